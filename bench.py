@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched polynomial products at n = 2^17 modulo 998244353.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the multiply path over one batch of synthetic products whose inputs
+and outputs are resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank per
+GPU) the batch is sharded by product with no data-path collective; the barrier and the
+max-over-ranks clock are the only communication.  Rank 0 prints one JSON line.
+"""
+import argparse
+import ctypes
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def cpu_baseline(n, p, min_seconds=12.0, max_reps=100000):
+    """The reference's OpenMP multiply (compiled from its own source into oracle/_ref) timed on this
+    host; falls back to this repo's port of the same algorithm when the reference build is absent."""
+    import numpy as np
+    from oracle_binding import Oracle, Reference
+    orc = Oracle()
+    a = orc.fill_random(n, p, 0x5EED0000); b = orc.fill_random(n, p, 0x5EED0001)
+    ref = Reference()
+    threads = 8  # NUM_THREADS of main_openMP.cc:15
+    if ref.openmp is not None:
+        kind, fn = "reference", (lambda: ref.openmp_ntt_multiply(a, b, p, threads))
+    else:
+        kind, fn = "port", (lambda: orc.ntt_multiply_openmp(a, b, p, threads))
+    want = orc.ntt_multiply(a, b, p)
+    got = fn(); fn()                      # warm-up (thread team start-up dominates the first call)
+    assert np.array_equal(got, want)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        fn(); reps += 1
+        el = time.perf_counter() - t0
+        if el >= min_seconds or reps >= max_reps:
+            break
+    return {"value": reps / el, "unit": "poly-mults/s", "cores": threads, "kind": kind,
+            "sample": f"{reps} products n={n} p={p} in {el:.1f} s, NTT_multiply_parallel (main_openMP.cc:176-217), {threads} OpenMP threads",
+            "host_cpus": os.cpu_count()}
+
+
+def load_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/traffic_*.json)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=131072)
+    ap.add_argument("--p", type=int, default=998244353)
+    ap.add_argument("--batch", type=int, default=256, help="products per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from ntt_amd._binding import load_product_library
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n, p, B = args.n, args.p, args.batch
+    L = 2 * n
+    lib = load_product_library()
+    lib.init(0)
+
+    gen = torch.Generator(device="cuda"); gen.manual_seed(0x5EED0000 + rank)
+    a = torch.randint(0, p, (B, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
+    b = torch.randint(0, p, (B, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
+    out = torch.zeros((B, L), dtype=torch.int32, device="cuda")
+    ws_bytes = lib.lib.ntt_workspace_bytes(n, p, B)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        st = lib.lib.ntt_poly_multiply_batched_device(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, p, B, n, n, L,
+                                                      ws.data_ptr(), ws_bytes, stream)
+        lib.check(st)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_kernel_events:
+        lib.lib.ntt_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # per-kernel durations from the HIP events recorded on the launch stream during the timed steps
+    kernels = {}
+    if not args.no_kernel_events:
+        names = ctypes.create_string_buffer(512)
+        ms = (ctypes.c_double * 16)(); cnt = (ctypes.c_int * 16)()
+        lib.lib.ntt_profile_read.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+        k = lib.lib.ntt_profile_read(names, 512, ms, cnt, 16)
+        labels = names.value.decode().split(",") if k > 0 else []
+        for i, lab in enumerate(labels):
+            kernels[lab] = {"avg_ms": ms[i] / max(cnt[i], 1), "launches": cnt[i]}
+        lib.lib.ntt_profile_enable(0)
+
+    # spot-check three products of this rank's batch against the oracle (outside the timed region)
+    verified = None
+    if rank == 0:
+        from oracle_binding import Oracle
+        orc = Oracle()
+        res = out.cpu().numpy()
+        ah, bh = a.cpu().numpy(), b.cpu().numpy()
+        verified = all(np.array_equal(res[r, :2 * n - 1].astype(np.uint64), orc.ntt_multiply(ah[r], bh[r], p)) for r in (0, 1, B - 1))
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = world * B / (elapsed / args.steps)
+        # Algorithmic bytes of a product under the two-pass model: 96*n.  Share per kernel: column pass of
+        # A and B (read 4n, write 8n each) 24n; fused core (second pass of both forward transforms, pointwise
+        # product, first pass of the inverse: 16n+16n read/write forward, 16n read + 8n write inverse) 56n,
+        # of which only 24n (read 16n, write 8n) must touch HBM; inverse column pass (read 8n, write 8n) 16n.
+        alg = {"k_fwd_strided": 24 * n * B, "k_core_mul": 56 * n * B, "k_inv_strided": 16 * n * B,
+               "k_fused8192": 16 * n * B, "k_small": 16 * n * B}
+        compulsory = {"k_fwd_strided": 24 * n * B, "k_core_mul": 24 * n * B, "k_inv_strided": 16 * n * B,
+                      "k_fused8192": 16 * n * B, "k_small": 16 * n * B}
+        roofline = None
+        if kernels:
+            dom = max(kernels, key=lambda k_: kernels[k_]["avg_ms"])
+            dur = kernels[dom]["avg_ms"] * 1e-3
+            achieved = compulsory[dom] / dur / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(dom),
+                        "bytes_per_launch": compulsory[dom], "avg_launch_ms": kernels[dom]["avg_ms"],
+                        "two_pass_model_bytes_per_launch": alg[dom],
+                        "kernels": {k_: {"avg_ms": v["avg_ms"], "launches": v["launches"],
+                                         "GBps_compulsory": compulsory[k_] / (v["avg_ms"] * 1e-3) / 1e9} for k_, v in kernels.items()},
+                        "path": {"bytes_per_product_two_pass_model": 96 * n,
+                                 "bytes_per_product_moved": sum(compulsory[k_] for k_ in kernels) // B,
+                                 "achieved_GBps_two_pass_model": value / world * 96 * n / 1e9,
+                                 "frac_two_pass_model": value / world * 96 * n / 1e9 / HBM_PEAK_GBS}}
+        line = {"metric": "poly-mults/sec at n=2^17 batched", "value": value, "unit": "poly-mults/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                "config": {"workload": f"batched poly_multiply n={n} p={p}, {B} products per GPU per step, "
+                                       f"inputs/outputs resident in HBM (config 2 of BASELINE.json, batched)",
+                           "n": n, "p": p, "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}"},
+                "verified_vs_oracle": verified, "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(n, p)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

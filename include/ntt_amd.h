@@ -1,0 +1,115 @@
+/*
+ * ntt_amd -- polynomial multiplication modulo NTT-friendly primes on AMD MI355X (gfx950).
+ *
+ * C ABI of libnttamd.so.  Plain pointers and sizes only; every entry point is
+ * what a binding for the reference's multiply path would call.  The library is
+ * HIP-only: there is no CPU fallback, and every call fails (status < 0, message
+ * in ntt_last_error()) when no GPU is usable.
+ *
+ * Conventions (same as the reference programs): a and b hold n coefficients in
+ * [0, p); the product has 2n-1 coefficients, each fully reduced to [0, p);
+ * p is prime with primitive root 3 and transform length L | p-1, where
+ * L = smallest power of two >= 2n-1 (L = 2n when n is a power of two).
+ * Moduli above 2^32 -- and any modulus that is not NTT-friendly -- go through
+ * four fixed 31-bit NTT primes and a 128-bit CRT merge.
+ *
+ * One caller at a time per process (the reference is single-threaded at this
+ * boundary too); calls on different devices may not overlap.
+ */
+#ifndef NTT_AMD_H
+#define NTT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes */
+#define NTT_OK 0
+#define NTT_ERR_ARG (-1)      /* bad size / pointer / modulus */
+#define NTT_ERR_MODULUS (-2)  /* modulus unsupported for this n (see ntt_last_error) */
+#define NTT_ERR_DEVICE (-3)   /* HIP runtime error or no GPU */
+#define NTT_ERR_WORKSPACE (-4)/* caller workspace too small */
+
+/* Library lifetime.  ntt_init(n_gpus) selects devices 0..n_gpus-1 (n_gpus <= 0: all visible);
+ * it replaces the reference's pool/global set-up calls (pthread pool creation main_pthread.cc:755-761,
+ * init_global_crt_values main_openMP.cc:337-357).  Optional: the first multiply initialises lazily. */
+int ntt_init(int n_gpus);
+void ntt_shutdown(void);
+int ntt_device_count(void);
+/* message for the last non-zero status on this thread ("" if none) */
+const char *ntt_last_error(void);
+
+/* Drop-in for the course skeleton's entry point `void poly_multiply(int *a, int *b, int *ab, int n, int p)`
+ * (main.cc:92-98, call site main.cc:1268-1269).  Writes ab[0..2n-2]; like every NTT path of the
+ * reference it overwrites rather than accumulates.  Aborts the process with a message on failure,
+ * because the reference signature has no error channel. */
+void poly_multiply(const int *a, const int *b, int *ab, int n, int p);
+
+/* Drop-in for the graded programs' 64-bit entry points: `NTT_multiply` (main_naive.cc:139-177) when
+ * p <= 2^32 and `CRT_NTT_multiply_serial` (main_naive.cc:178-230) when p > 2^32 -- the dispatch of
+ * main_naive.cc:253-257 (and main_openMP.cc:431-435, main_pthread.cc:778-782, main_mpi_CRT.cc:578).
+ * Host pointers, synchronous.  Aborts on failure like poly_multiply. */
+void poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p);
+
+/* Status-returning forms of the two calls above (same arguments, same results). */
+int ntt_poly_multiply_i32(const int *a, const int *b, int *ab, int n, int p);
+int ntt_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p);
+
+/* Batch of independent products with 32-bit residues, host memory.  a, b: batch rows of n values;
+ * ab: batch rows of 2n-1 values, all contiguous.  The batch is split into contiguous shards over
+ * n_gpus devices (<= 0: all initialised devices) with no inter-device communication -- the
+ * replacement for running the reference once per product. */
+int ntt_poly_multiply_batched(const uint32_t *a, const uint32_t *b, uint32_t *ab, int n, uint32_t p,
+                              size_t batch, int n_gpus);
+
+/* Same, 64-bit coefficients and any modulus (CRT path when p > 2^32). */
+int ntt_poly_multiply_batched_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p,
+                                  size_t batch, int n_gpus);
+
+/* Device-resident batch on the current HIP device: d_a, d_b, d_ab are device pointers, rows
+ * a_stride / b_stride / ab_stride elements apart (>= n, n, 2n-1).  Work is enqueued on `stream`
+ * (a hipStream_t passed as void*; NULL = default stream) and the call returns without
+ * synchronising.  `workspace` is device memory of at least ntt_workspace_bytes(n, p, batch) bytes
+ * (NULL: the library uses and grows its own).  This is the path the benchmark times. */
+size_t ntt_workspace_bytes(int n, uint64_t p, size_t batch);
+int ntt_poly_multiply_batched_device(const uint32_t *d_a, const uint32_t *d_b, uint32_t *d_ab, int n, uint32_t p,
+                                     size_t batch, size_t a_stride, size_t b_stride, size_t ab_stride,
+                                     void *workspace, size_t workspace_bytes, void *stream);
+int ntt_poly_multiply_batched_device_u64(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_ab, int n, uint64_t p,
+                                         size_t batch, size_t a_stride, size_t b_stride, size_t ab_stride,
+                                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* The CRT recombination on its own (the merge loop of main_naive.cc:216-223 / the slice merge of
+ * main_mpi_CRT.cc:512-522): d_res holds the four residue vectors (moduli 1004535809, 1224736769,
+ * 469762049, 998244353 in this order), res_stride elements apart, count values each; writes
+ * d_out[i] = (CRT(res[0..3][i]) mod M) mod p.  Device pointers, enqueued on `stream`. */
+int ntt_crt_merge_device(const uint32_t *d_res, size_t res_stride, uint64_t *d_out, size_t count, uint64_t p,
+                         void *stream);
+
+/* Residue products for one CRT prime only (prime_index 0..3, order as above): d_res[row] =
+ * (a[row] mod q) * (b[row] mod q) mod q, the per-rank work of main_mpi_CRT.cc:470-492.  Lets a
+ * multi-GPU caller place primes on different devices and exchange residues itself. */
+int ntt_crt_residue_product_device(const uint64_t *d_a, const uint64_t *d_b, uint32_t *d_res, int n, int prime_index,
+                                   size_t batch, size_t a_stride, size_t b_stride, size_t res_stride,
+                                   void *workspace, size_t workspace_bytes, void *stream);
+uint32_t ntt_crt_prime(int prime_index);
+
+/* Per-kernel timing for benchmarks (no counterpart in the reference, whose only clock is the
+ * chrono pair around the multiply, main_naive.cc:251-261).  While enabled, every kernel launch is
+ * bracketed by HIP events on the stream it is launched on.  ntt_profile_read waits for the
+ * recorded events, writes a comma-separated list of kernel labels into names and, per label,
+ * the summed duration in ms and the number of launches; returns the number of labels. */
+int ntt_profile_enable(int on);
+int ntt_profile_read(char *names, size_t names_len, double *total_ms, int *launches, int max_kernels);
+
+/* Name and per-call launch count of the kernels a (n, p) product uses, for profiling tools:
+ * writes a comma-separated list into buf. */
+int ntt_describe_plan(int n, uint64_t p, char *buf, size_t buf_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NTT_AMD_H */

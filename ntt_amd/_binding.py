@@ -1,0 +1,129 @@
+"""ctypes binding of the libnttamd C ABI (include/ntt_amd.h).
+
+The binding class only declares signatures and converts arguments; all
+arithmetic happens inside the shared library.  `load_product_library()` loads
+the HIP build that ships in this package and raises if it is missing -- there
+is no software fallback.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+NTT_OK = 0
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PRODUCT_LIB = os.path.join(_HERE, "libnttamd.so")
+
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+
+EXPORTS = [
+    "ntt_init", "ntt_shutdown", "ntt_device_count", "ntt_last_error",
+    "poly_multiply", "poly_multiply_u64", "ntt_poly_multiply_i32", "ntt_poly_multiply_u64",
+    "ntt_poly_multiply_batched", "ntt_poly_multiply_batched_u64",
+    "ntt_workspace_bytes", "ntt_poly_multiply_batched_device", "ntt_poly_multiply_batched_device_u64",
+    "ntt_crt_merge_device", "ntt_crt_residue_product_device", "ntt_crt_prime", "ntt_describe_plan",
+]
+
+
+class NttError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"ntt_amd status {status}: {message}")
+        self.status = status
+
+
+class NttLibrary:
+    """Typed view of one loaded libnttamd shared object."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc, gfx950). ntt_amd has no CPU fallback.")
+        self.path = path
+        self.lib = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+        L = self.lib
+        L.ntt_init.argtypes = [ctypes.c_int]; L.ntt_init.restype = ctypes.c_int
+        L.ntt_shutdown.argtypes = []; L.ntt_shutdown.restype = None
+        L.ntt_device_count.argtypes = []; L.ntt_device_count.restype = ctypes.c_int
+        L.ntt_last_error.argtypes = []; L.ntt_last_error.restype = ctypes.c_char_p
+        L.poly_multiply.argtypes = [c_i32p, c_i32p, c_i32p, ctypes.c_int, ctypes.c_int]; L.poly_multiply.restype = None
+        L.poly_multiply_u64.argtypes = [c_u64p, c_u64p, c_u64p, ctypes.c_int, ctypes.c_uint64]; L.poly_multiply_u64.restype = None
+        L.ntt_poly_multiply_i32.argtypes = [c_i32p, c_i32p, c_i32p, ctypes.c_int, ctypes.c_int]; L.ntt_poly_multiply_i32.restype = ctypes.c_int
+        L.ntt_poly_multiply_u64.argtypes = [c_u64p, c_u64p, c_u64p, ctypes.c_int, ctypes.c_uint64]; L.ntt_poly_multiply_u64.restype = ctypes.c_int
+        L.ntt_poly_multiply_batched.argtypes = [c_u32p, c_u32p, c_u32p, ctypes.c_int, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_int]
+        L.ntt_poly_multiply_batched.restype = ctypes.c_int
+        L.ntt_poly_multiply_batched_u64.argtypes = [c_u64p, c_u64p, c_u64p, ctypes.c_int, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int]
+        L.ntt_poly_multiply_batched_u64.restype = ctypes.c_int
+        L.ntt_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_size_t]; L.ntt_workspace_bytes.restype = ctypes.c_size_t
+        dev_args = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.ntt_poly_multiply_batched_device.argtypes = dev_args + [ctypes.c_uint32] + [ctypes.c_size_t] * 4 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.ntt_poly_multiply_batched_device.restype = ctypes.c_int
+        L.ntt_poly_multiply_batched_device_u64.argtypes = dev_args + [ctypes.c_uint64] + [ctypes.c_size_t] * 4 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.ntt_poly_multiply_batched_device_u64.restype = ctypes.c_int
+        L.ntt_crt_merge_device.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_void_p]
+        L.ntt_crt_merge_device.restype = ctypes.c_int
+        L.ntt_crt_residue_product_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_size_t] * 4 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.ntt_crt_residue_product_device.restype = ctypes.c_int
+        L.ntt_crt_prime.argtypes = [ctypes.c_int]; L.ntt_crt_prime.restype = ctypes.c_uint32
+        L.ntt_describe_plan.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t]; L.ntt_describe_plan.restype = ctypes.c_int
+
+    # -- helpers ---------------------------------------------------------
+    def check(self, status):
+        if status != NTT_OK:
+            raise NttError(status, self.lib.ntt_last_error().decode("utf-8", "replace"))
+
+    def last_error(self):
+        return self.lib.ntt_last_error().decode("utf-8", "replace")
+
+    def init(self, n_gpus=0):
+        self.check(self.lib.ntt_init(int(n_gpus)))
+
+    def shutdown(self):
+        self.lib.ntt_shutdown()
+
+    def describe_plan(self, n, p):
+        buf = ctypes.create_string_buffer(256)
+        self.check(self.lib.ntt_describe_plan(int(n), int(p), buf, 256))
+        return buf.value.decode()
+
+    # -- host-memory products ---------------------------------------------
+    def multiply_i32(self, a, b, p):
+        a = np.ascontiguousarray(a, dtype=np.int32); b = np.ascontiguousarray(b, dtype=np.int32)
+        n = a.shape[-1]
+        out = np.zeros(2 * n - 1, dtype=np.int32)
+        self.check(self.lib.ntt_poly_multiply_i32(a.ctypes.data_as(c_i32p), b.ctypes.data_as(c_i32p), out.ctypes.data_as(c_i32p), n, int(p)))
+        return out
+
+    def multiply_u64(self, a, b, p):
+        a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)
+        n = a.shape[-1]
+        out = np.zeros(2 * n - 1, dtype=np.uint64)
+        self.check(self.lib.ntt_poly_multiply_u64(a.ctypes.data_as(c_u64p), b.ctypes.data_as(c_u64p), out.ctypes.data_as(c_u64p), n, int(p)))
+        return out
+
+    def multiply_batched(self, a, b, p, n_gpus=0):
+        a = np.ascontiguousarray(a, dtype=np.uint32); b = np.ascontiguousarray(b, dtype=np.uint32)
+        batch, n = a.shape
+        out = np.zeros((batch, 2 * n - 1), dtype=np.uint32)
+        self.check(self.lib.ntt_poly_multiply_batched(a.ctypes.data_as(c_u32p), b.ctypes.data_as(c_u32p), out.ctypes.data_as(c_u32p), n, int(p), batch, int(n_gpus)))
+        return out
+
+    def multiply_batched_u64(self, a, b, p, n_gpus=0):
+        a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)
+        batch, n = a.shape
+        out = np.zeros((batch, 2 * n - 1), dtype=np.uint64)
+        self.check(self.lib.ntt_poly_multiply_batched_u64(a.ctypes.data_as(c_u64p), b.ctypes.data_as(c_u64p), out.ctypes.data_as(c_u64p), n, int(p), batch, int(n_gpus)))
+        return out
+
+
+_product = None
+
+
+def load_product_library():
+    """The HIP library shipped in this package (raises when it has not been built)."""
+    global _product
+    if _product is None:
+        _product = NttLibrary(PRODUCT_LIB)
+    return _product

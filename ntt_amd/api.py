@@ -1,0 +1,90 @@
+"""Python face of the drop-in boundary plus the reference's text harness.
+
+Function names and argument meaning follow the reference: `poly_multiply`
+(main.cc:92-98), the 64-bit dispatch of main_naive.cc:253-257, and the
+`fRead` / `fCheck` / `fWrite` file conventions (main_naive.cc:13-67).
+"""
+import os
+import time
+
+import numpy as np
+
+from ._binding import load_product_library
+
+
+def poly_multiply(a, b, n, p):
+    """ab = a*b mod p for int32 coefficient arrays of length n (main.cc:92 signature)."""
+    a = np.asarray(a, dtype=np.int32)[:n]; b = np.asarray(b, dtype=np.int32)[:n]
+    return load_product_library().multiply_i32(a, b, p)
+
+
+def poly_multiply_u64(a, b, n, p):
+    """64-bit entry point: direct NTT when p fits, four-prime CRT otherwise (main_naive.cc:253-257)."""
+    a = np.asarray(a, dtype=np.uint64)[:n]; b = np.asarray(b, dtype=np.uint64)[:n]
+    return load_product_library().multiply_u64(a, b, p)
+
+
+def poly_multiply_batched(a, b, p, n_gpus=0):
+    """Rows of a and b are independent products; the batch is sharded over n_gpus devices."""
+    return load_product_library().multiply_batched(a, b, p, n_gpus)
+
+
+def poly_multiply_batched_u64(a, b, p, n_gpus=0):
+    return load_product_library().multiply_batched_u64(a, b, p, n_gpus)
+
+
+# ---- text harness (main_naive.cc:13-67) ------------------------------------
+def read_in_file(path):
+    """`n p` then n coefficients of a and n of b, whitespace separated."""
+    with open(path, "rb") as f:
+        tok = f.read().split()
+    n, p = int(tok[0]), int(tok[1])
+    vals = np.array(tok[2:2 + 2 * n], dtype=np.uint64)
+    if vals.size != 2 * n:
+        raise ValueError(f"{path}: expected {2 * n} coefficients, found {vals.size}")
+    return n, p, vals[:n].copy(), vals[n:].copy()
+
+
+def read_out_file(path, n):
+    with open(path, "rb") as f:
+        tok = f.read().split()
+    vals = np.array(tok[:2 * n - 1], dtype=np.uint64)
+    if vals.size != 2 * n - 1:
+        raise ValueError(f"{path}: expected {2 * n - 1} values, found {vals.size}")
+    return vals
+
+
+def write_out_file(path, ab):
+    """One value per line, as fWrite does."""
+    with open(path, "w") as f:
+        f.write("\n".join(str(int(v)) for v in ab))
+        f.write("\n")
+
+
+def run_harness(data_dir, out_dir=None, ids=range(0, 5), stream=None):
+    """Loop of the reference main (main_naive.cc:243-268): read <id>.in, multiply, compare
+    with <id>.out, print the same two lines, optionally write <out_dir>/<id>.out.
+    Missing inputs are skipped (the reference reads uninitialised sizes instead).
+    Returns {id: bool correct}."""
+    import sys
+    stream = stream or sys.stdout
+    results = {}
+    for i in ids:
+        fin = os.path.join(data_dir, f"{i}.in")
+        if not os.path.exists(fin):
+            continue
+        n, p, a, b = read_in_file(fin)
+        t0 = time.perf_counter()
+        ab = poly_multiply_u64(a, b, n, p)
+        ms = (time.perf_counter() - t0) * 1e3
+        ok = None
+        fout = os.path.join(data_dir, f"{i}.out")
+        if os.path.exists(fout):
+            ok = bool(np.array_equal(read_out_file(fout, n), ab))
+            print("多项式乘法结果正确" if ok else "多项式乘法结果错误", file=stream)
+        print(f"average latency for n = {n} p = {p} : {ms:g} (us) ", file=stream)
+        if out_dir:
+            os.makedirs(out_dir, exist_ok=True)
+            write_out_file(os.path.join(out_dir, f"{i}.out"), ab)
+        results[i] = ok
+    return results

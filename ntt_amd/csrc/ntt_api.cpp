@@ -1,0 +1,563 @@
+// C ABI of libnttamd.so: plan cache, workspace management, kernel launches.
+// Compiled as HIP for gfx950 (the product) and, with NTT_CPU_TWIN, as plain C++
+// over a test-only HIP stand-in so the host logic and kernel index arithmetic
+// can be exercised without a GPU.  The product build contains no CPU compute path.
+#ifdef NTT_CPU_TWIN
+#include "hip_cpu_shim.h"
+#else
+#include <hip/hip_runtime.h>
+#define NTT_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
+#endif
+// launch bracketed by profiling events when ntt_profile_enable(1) is in effect
+#define NTT_LAUNCH_P(label, kernel, grid, block, stream, ...)      \
+    do {                                                           \
+        prof_begin(label, stream);                                 \
+        NTT_LAUNCH(kernel, grid, block, stream, __VA_ARGS__);      \
+        prof_end(stream);                                          \
+    } while (0)
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ntt_amd.h"
+#include "ntt_kernels.h"
+#include "ntt_plan.h"
+
+using namespace nttamd;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(NTT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return NTT_OK;
+        if (ptr) { hipError_t e = hipFree(ptr); (void)e; ptr = nullptr; bytes = 0; }
+        HIP_TRY(hipMalloc(&ptr, need));
+        bytes = need;
+        return NTT_OK;
+    }
+    void release() {
+        if (ptr) { hipError_t e = hipFree(ptr); (void)e; }
+        ptr = nullptr; bytes = 0;
+    }
+};
+
+struct Plan {
+    PlanHost h;  // host image without the big vectors after upload (kept: small)
+    DevBuf tables;
+    const uint32_t *twF = nullptr, *twI = nullptr, *ow = nullptr, *T1 = nullptr, *T3 = nullptr;
+    CoreTables core{};
+};
+
+struct Device {
+    int id = 0;
+    hipStream_t stream = nullptr;
+    std::map<std::pair<uint32_t, int>, std::unique_ptr<Plan>> plans;
+    DevBuf work;     // library-owned workspace
+    DevBuf io_a, io_b, io_out;  // staging for the host-pointer entry points
+};
+
+std::map<int, std::unique_ptr<Device>> g_devs;  // created on first use of each device
+int g_visible = 0;                                // devices this process may use (ntt_init)
+bool g_inited = false;
+
+int do_init(int n_gpus) {
+    if (g_inited) {
+        if (n_gpus > 0 && n_gpus < g_visible) g_visible = n_gpus;
+        return NTT_OK;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(NTT_ERR_DEVICE, "no usable HIP device (this library has no CPU fallback)");
+    g_visible = (n_gpus > 0 && n_gpus < count) ? n_gpus : count;
+    g_inited = true;
+    return NTT_OK;
+}
+
+int get_device(int id, Device** out) {
+    auto it = g_devs.find(id);
+    if (it != g_devs.end()) { *out = it->second.get(); return NTT_OK; }
+    std::unique_ptr<Device> dev(new Device());
+    dev->id = id;
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(id));
+    HIP_TRY(hipStreamCreate(&dev->stream));
+    HIP_TRY(hipSetDevice(prev));
+    *out = dev.get();
+    g_devs[id] = std::move(dev);
+    return NTT_OK;
+}
+
+int current_device(Device** out) {
+    int d = 0;
+    HIP_TRY(hipGetDevice(&d));
+    return get_device(d, out);
+}
+
+// ---- optional per-kernel timing with HIP events on the launch stream ----
+struct ProfRec { const char* label; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+void prof_begin(const char* label, hipStream_t st) {
+    if (!g_prof_on) return;
+    ProfRec r; r.label = label; r.e0 = nullptr; r.e1 = nullptr;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    if (hipEventRecord(r.e0, st) != hipSuccess) return;
+    g_prof.push_back(r);
+}
+void prof_end(hipStream_t st) {
+    if (!g_prof_on || g_prof.empty()) return;
+    hipError_t e = hipEventRecord(g_prof.back().e1, st);
+    (void)e;
+}
+
+// upload helper: appends a vector to a staging image, returns its offset (16-byte aligned)
+size_t stage(std::vector<uint32_t>& img, const std::vector<uint32_t>& v) {
+    while (img.size() % 4) img.push_back(0);
+    size_t off = img.size();
+    img.insert(img.end(), v.begin(), v.end());
+    return off;
+}
+
+int get_plan(Device* dev, uint32_t p, int logL, Plan** out) {
+    auto key = std::make_pair(p, logL);
+    auto it = dev->plans.find(key);
+    if (it != dev->plans.end()) { *out = it->second.get(); return NTT_OK; }
+    std::unique_ptr<Plan> pl(new Plan());
+    std::string err;
+    if (!build_plan_host(p, logL, pl->h, &err)) return fail(NTT_ERR_MODULUS, err);
+    std::vector<uint32_t> img;
+    PlanHost& h = pl->h;
+    size_t o_twF = stage(img, h.twF), o_twI = stage(img, h.twI), o_ow = stage(img, h.ow);
+    size_t o_1F = stage(img, h.tw1F), o_2F = stage(img, h.tw2F), o_1I = stage(img, h.tw1I), o_2I = stage(img, h.tw2I);
+    size_t o_T1 = stage(img, h.T1), o_T3 = stage(img, h.T3);
+    if (img.empty()) img.push_back(0);
+    int rc = pl->tables.ensure(img.size() * sizeof(uint32_t));
+    if (rc != NTT_OK) return rc;
+    HIP_TRY(hipMemcpy(pl->tables.ptr, img.data(), img.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    const uint32_t* base = (const uint32_t*)pl->tables.ptr;
+    pl->twF = base + o_twF; pl->twI = base + o_twI; pl->ow = base + o_ow;
+    pl->core.tw1F = base + o_1F; pl->core.tw2F = base + o_2F; pl->core.tw1I = base + o_1I; pl->core.tw2I = base + o_2I;
+    pl->T1 = base + o_T1; pl->T3 = base + o_T3;
+    // the big host vectors are no longer needed
+    std::vector<uint32_t>().swap(h.T1); std::vector<uint32_t>().swap(h.T3);
+    *out = pl.get();
+    dev->plans[key] = std::move(pl);
+    return NTT_OK;
+}
+
+size_t pipeline_workspace_bytes(int logL, size_t batch) {
+    if (logL <= 13) return 0;
+    return 2 * batch * ((size_t)1 << logL) * sizeof(uint32_t);
+}
+
+template <int Q, bool LZ, typename TIn, typename TOut>
+void launch_multipass(const Plan& pl, const TIn* a, const TIn* b, TOut* out, int n, size_t batch, size_t sa, size_t sb,
+                      size_t so, uint32_t* tmpA, uint32_t* tmpB, hipStream_t st) {
+    const int C = CORE_N;
+    const unsigned chunks = C / 256;
+    NTT_LAUNCH_P("k_fwd_strided", (k_fwd_strided<Q, LZ, true, TIn>), dim3((unsigned)(chunks * batch), 1, 2), dim3(256), st, a, b, sa, sb, n,
+               tmpA, tmpB, C, pl.T1, pl.h.fc);
+    NTT_LAUNCH_P("k_core_mul", (k_core_mul<LZ>), dim3((unsigned)(batch << Q)), dim3(CORE_T), st, (const uint32_t*)tmpA,
+               (const uint32_t*)tmpB, tmpA, pl.h.fc, pl.core);
+    NTT_LAUNCH_P("k_inv_strided", (k_inv_strided<Q, LZ, true, TOut>), dim3((unsigned)(chunks * batch)), dim3(256), st,
+               (const uint32_t*)tmpA, out, so, 2 * n - 1, C, pl.T3, pl.h.fc);
+}
+
+template <bool LZ, typename TIn, typename TOut>
+int launch_product(const Plan& pl, const TIn* a, const TIn* b, TOut* out, int n, size_t batch, size_t sa, size_t sb,
+                   size_t so, void* ws, hipStream_t st) {
+    const int n_out = 2 * n - 1;
+    switch (pl.h.kind) {
+        case PLAN_SMALL:
+            NTT_LAUNCH_P("k_small", (k_small<LZ, TIn, TOut>), dim3((unsigned)batch), dim3(256), st, a, b, out, sa, sb, so, n, n_out,
+                       pl.h.logL, pl.twF, pl.twI, pl.h.scale_m, pl.h.fc);
+            break;
+        case PLAN_FUSED8192:
+            NTT_LAUNCH_P("k_fused8192", (k_fused8192<LZ, TIn, TOut>), dim3((unsigned)batch), dim3(CORE_T), st, a, b, out, sa, sb, so, n,
+                       n_out, pl.ow, pl.h.fc, pl.core);
+            break;
+        case PLAN_MULTIPASS: {
+            uint32_t* tmpA = (uint32_t*)ws;
+            uint32_t* tmpB = tmpA + batch * ((size_t)1 << pl.h.logL);
+            switch (pl.h.Q) {
+                case 2: launch_multipass<2, LZ>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st); break;
+                case 3: launch_multipass<3, LZ>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st); break;
+                case 4: launch_multipass<4, LZ>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st); break;
+                case 5: launch_multipass<5, LZ>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st); break;
+                case 6: launch_multipass<6, LZ>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st); break;
+                default: return fail(NTT_ERR_ARG, "unsupported strided radix");
+            }
+            break;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+
+// One modulus < 2^31, device-resident operands of type TIn, output TOut.
+template <typename TIn, typename TOut>
+int product_device(Device* dev, const TIn* a, const TIn* b, TOut* out, int n, uint32_t p, size_t batch, size_t sa, size_t sb,
+                   size_t so, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int logL = transform_log2(n);
+    Plan* pl = nullptr;
+    int rc = get_plan(dev, p, logL, &pl);
+    if (rc != NTT_OK) return rc;
+    const size_t need = pipeline_workspace_bytes(logL, batch);
+    if (need) {
+        if (ws) {
+            if (ws_bytes < need) return fail(NTT_ERR_WORKSPACE, "workspace too small");
+        } else {
+            rc = dev->work.ensure(need);
+            if (rc != NTT_OK) return rc;
+            ws = dev->work.ptr;
+        }
+    }
+    if (pl->h.lazy) return launch_product<true>(*pl, a, b, out, n, batch, sa, sb, so, ws, st);
+    return launch_product<false>(*pl, a, b, out, n, batch, sa, sb, so, ws, st);
+}
+
+int make_crt_consts(uint64_t p, CrtConsts* c) {
+    if (p < 2) return fail(NTT_ERR_ARG, "modulus must be at least 2");
+    CrtHost h = crt_host_consts();
+    for (int i = 0; i < 4; ++i) {
+        c->q[i] = kCrtPrimes[i];
+        c->nq[i] = h_neg_inv32(kCrtPrimes[i]);
+        c->minv_m[i] = h_mont(h.Mi_inv[i], kCrtPrimes[i]);
+        c->mi_lo[i] = (uint64_t)h.Mi[i];
+        c->mi_hi[i] = (uint32_t)(h.Mi[i] >> 64);
+    }
+    c->M_lo = (uint64_t)h.M; c->M_hi = (uint64_t)(h.M >> 64);
+    c->p = p;
+    c->shift = __builtin_clzll(p);
+    c->d = p << c->shift;
+    c->v = (uint64_t)((~(u128)0) / c->d - ((u128)1 << 64));
+    return NTT_OK;
+}
+
+bool direct_path_ok(uint64_t p, int logL) { return p < (1ull << 31) && modulus_is_ntt_friendly(p, logL); }
+
+size_t crt_workspace_bytes(int logL, size_t batch) {
+    const size_t L = (size_t)1 << logL;
+    return pipeline_workspace_bytes(logL, batch) + 4 * batch * L * sizeof(uint32_t);
+}
+
+// Any modulus through the four CRT primes: device-resident 64-bit operands.
+int crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, uint64_t* out, int n, uint64_t p, size_t batch,
+                       size_t sa, size_t sb, size_t so, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int logL = transform_log2(n);
+    if (!crt_bound_ok(n, p))
+        return fail(NTT_ERR_MODULUS, "n*(p-1)^2 exceeds the product of the four CRT primes: result would not be exact");
+    if (logL > 21) return fail(NTT_ERR_MODULUS, "CRT primes support transform lengths up to 2^21");
+    const size_t need = crt_workspace_bytes(logL, batch);
+    if (ws) {
+        if (ws_bytes < need) return fail(NTT_ERR_WORKSPACE, "workspace too small");
+    } else {
+        int rc = dev->work.ensure(need);
+        if (rc != NTT_OK) return rc;
+        ws = dev->work.ptr;
+    }
+    const size_t L = (size_t)1 << logL;
+    const size_t pipe = pipeline_workspace_bytes(logL, batch);
+    uint32_t* res = (uint32_t*)((char*)ws + pipe);
+    const size_t res_stride = batch * L;
+    for (int i = 0; i < 4; ++i) {
+        int rc = product_device<uint64_t, uint32_t>(dev, a, b, res + i * res_stride, n, kCrtPrimes[i], batch, sa, sb, L, ws,
+                                                    pipe, st);
+        if (rc != NTT_OK) return rc;
+    }
+    CrtConsts c;
+    int rc = make_crt_consts(p, &c);
+    if (rc != NTT_OK) return rc;
+    const size_t count = (size_t)(2 * n - 1);
+    NTT_LAUNCH_P("k_crt_merge", k_crt_merge, dim3((unsigned)((count + 255) / 256), (unsigned)batch), dim3(256), st, (const uint32_t*)res,
+               res_stride, out, count, batch, so, L, c);
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+
+int check_args(const void* a, const void* b, const void* ab, int n, size_t batch) {
+    if (!a || !b || !ab) return fail(NTT_ERR_ARG, "null pointer");
+    if (n < 1) return fail(NTT_ERR_ARG, "n must be at least 1");
+    if (batch > 0 && transform_log2(n) > MAX_LOG_L) return fail(NTT_ERR_ARG, "n too large");
+    if (batch >= (1ull << 31) / 64) return fail(NTT_ERR_ARG, "batch too large for one launch");
+    return NTT_OK;
+}
+
+// host-pointer driver for one device: H2D, run, D2H (synchronous)
+template <typename T, typename F>
+int run_host_shard(Device* dev, const T* a, const T* b, T* ab, int n, size_t batch, F&& run) {
+    if (batch == 0) return NTT_OK;
+    HIP_TRY(hipSetDevice(dev->id));
+    const size_t in_bytes = batch * (size_t)n * sizeof(T), out_bytes = batch * (size_t)(2 * n - 1) * sizeof(T);
+    int rc;
+    if ((rc = dev->io_a.ensure(in_bytes)) != NTT_OK) return rc;
+    if ((rc = dev->io_b.ensure(in_bytes)) != NTT_OK) return rc;
+    if ((rc = dev->io_out.ensure(out_bytes)) != NTT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(dev->io_a.ptr, a, in_bytes, hipMemcpyHostToDevice, dev->stream));
+    HIP_TRY(hipMemcpyAsync(dev->io_b.ptr, b, in_bytes, hipMemcpyHostToDevice, dev->stream));
+    rc = run(dev, (const T*)dev->io_a.ptr, (const T*)dev->io_b.ptr, (T*)dev->io_out.ptr, batch);
+    if (rc != NTT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(ab, dev->io_out.ptr, out_bytes, hipMemcpyDeviceToHost, dev->stream));
+    return NTT_OK;
+}
+
+template <typename T, typename F>
+int run_host_sharded(const T* a, const T* b, T* ab, int n, size_t batch, int n_gpus, F&& run) {
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    int G = g_visible;
+    if (n_gpus > 0 && n_gpus < G) G = n_gpus;
+    if ((size_t)G > batch) G = batch ? (int)batch : 1;
+    int home = 0;
+    HIP_TRY(hipGetDevice(&home));
+    const size_t per = (batch + G - 1) / G;
+    std::vector<Device*> used;
+    for (int g = 0; g < G; ++g) {
+        const size_t lo = (size_t)g * per, hi = lo + per < batch ? lo + per : batch;
+        if (lo >= hi) break;
+        Device* dev = nullptr;
+        // a single-device call runs on the caller's current device, a sharded one on devices 0..G-1
+        rc = get_device(G == 1 ? home : g, &dev);
+        if (rc != NTT_OK) break;
+        rc = run_host_shard(dev, a + lo * n, b + lo * n, ab + lo * (size_t)(2 * n - 1), n, hi - lo, run);
+        if (rc != NTT_OK) break;
+        used.push_back(dev);
+    }
+    int rc2 = NTT_OK;
+    for (Device* dev : used) {
+        hipError_t e = hipSetDevice(dev->id);
+        if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+        if (e != hipSuccess && rc2 == NTT_OK) rc2 = fail(NTT_ERR_DEVICE, std::string("stream sync: ") + hipGetErrorString(e));
+    }
+    hipError_t e0 = hipSetDevice(home);
+    (void)e0;
+    return rc != NTT_OK ? rc : rc2;
+}
+
+void die(const char* fn) {
+    fprintf(stderr, "%s failed: %s\n", fn, g_err.c_str());
+    abort();
+}
+
+}  // namespace
+
+extern "C" {
+
+int ntt_init(int n_gpus) { return do_init(n_gpus); }
+
+void ntt_shutdown(void) {
+    for (auto& kvd : g_devs) {
+        Device* dev = kvd.second.get();
+        hipError_t e = hipSetDevice(dev->id);
+        (void)e;
+        for (auto& kv : dev->plans) kv.second->tables.release();
+        dev->plans.clear();
+        dev->work.release(); dev->io_a.release(); dev->io_b.release(); dev->io_out.release();
+        if (dev->stream) { e = hipStreamDestroy(dev->stream); (void)e; }
+    }
+    g_devs.clear();
+    g_inited = false;
+}
+
+int ntt_device_count(void) { return g_inited ? g_visible : 0; }
+
+const char* ntt_last_error(void) { return g_err.c_str(); }
+
+uint32_t ntt_crt_prime(int i) { return (i >= 0 && i < 4) ? kCrtPrimes[i] : 0; }
+
+size_t ntt_workspace_bytes(int n, uint64_t p, size_t batch) {
+    if (n < 1) return 0;
+    const int logL = transform_log2(n);
+    if (logL > MAX_LOG_L) return 0;
+    return direct_path_ok(p, logL) ? pipeline_workspace_bytes(logL, batch) : crt_workspace_bytes(logL, batch);
+}
+
+int ntt_poly_multiply_batched_device(const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_ab, int n, uint32_t p, size_t batch,
+                                     size_t a_stride, size_t b_stride, size_t ab_stride, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    int rc = check_args(d_a, d_b, d_ab, n, batch);
+    if (rc != NTT_OK) return rc;
+    if (a_stride < (size_t)n || b_stride < (size_t)n || ab_stride < (size_t)(2 * n - 1)) return fail(NTT_ERR_ARG, "row stride too small");
+    if ((rc = do_init(0)) != NTT_OK) return rc;
+    if (batch == 0) return NTT_OK;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    if (!direct_path_ok(p, transform_log2(n))) {
+        std::string why;
+        modulus_is_ntt_friendly(p, transform_log2(n), &why);
+        return fail(NTT_ERR_MODULUS, "32-bit batched path needs an NTT-friendly modulus: " + why);
+    }
+    return product_device<uint32_t, uint32_t>(dev, d_a, d_b, d_ab, n, p, batch, a_stride, b_stride, ab_stride, workspace,
+                                              workspace_bytes, (hipStream_t)stream);
+}
+
+int ntt_poly_multiply_batched_device_u64(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_ab, int n, uint64_t p,
+                                         size_t batch, size_t a_stride, size_t b_stride, size_t ab_stride, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    int rc = check_args(d_a, d_b, d_ab, n, batch);
+    if (rc != NTT_OK) return rc;
+    if (a_stride < (size_t)n || b_stride < (size_t)n || ab_stride < (size_t)(2 * n - 1)) return fail(NTT_ERR_ARG, "row stride too small");
+    if ((rc = do_init(0)) != NTT_OK) return rc;
+    if (batch == 0) return NTT_OK;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    if (direct_path_ok(p, transform_log2(n)))
+        return product_device<uint64_t, uint64_t>(dev, d_a, d_b, d_ab, n, (uint32_t)p, batch, a_stride, b_stride, ab_stride,
+                                                  workspace, workspace_bytes, (hipStream_t)stream);
+    return crt_product_device(dev, d_a, d_b, d_ab, n, p, batch, a_stride, b_stride, ab_stride, workspace, workspace_bytes,
+                              (hipStream_t)stream);
+}
+
+int ntt_crt_merge_device(const uint32_t* d_res, size_t res_stride, uint64_t* d_out, size_t count, uint64_t p, void* stream) {
+    if (!d_res || !d_out) return fail(NTT_ERR_ARG, "null pointer");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    if (count == 0) return NTT_OK;
+    CrtConsts c;
+    if ((rc = make_crt_consts(p, &c)) != NTT_OK) return rc;
+    NTT_LAUNCH(k_crt_merge, dim3((unsigned)((count + 255) / 256), 1), dim3(256), (hipStream_t)stream, d_res, res_stride, d_out,
+               count, (size_t)1, count, (size_t)0, c);
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+
+int ntt_crt_residue_product_device(const uint64_t* d_a, const uint64_t* d_b, uint32_t* d_res, int n, int prime_index,
+                                   size_t batch, size_t a_stride, size_t b_stride, size_t res_stride, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    int rc = check_args(d_a, d_b, d_res, n, batch);
+    if (rc != NTT_OK) return rc;
+    if (prime_index < 0 || prime_index > 3) return fail(NTT_ERR_ARG, "prime_index must be 0..3");
+    if (a_stride < (size_t)n || b_stride < (size_t)n || res_stride < (size_t)(2 * n - 1)) return fail(NTT_ERR_ARG, "row stride too small");
+    if ((rc = do_init(0)) != NTT_OK) return rc;
+    if (batch == 0) return NTT_OK;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    return product_device<uint64_t, uint32_t>(dev, d_a, d_b, d_res, n, kCrtPrimes[prime_index], batch, a_stride, b_stride,
+                                              res_stride, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ntt_poly_multiply_batched(const uint32_t* a, const uint32_t* b, uint32_t* ab, int n, uint32_t p, size_t batch, int n_gpus) {
+    int rc = check_args(a, b, ab, n, batch);
+    if (rc != NTT_OK) return rc;
+    if (!direct_path_ok(p, transform_log2(n))) {
+        std::string why;
+        modulus_is_ntt_friendly(p, transform_log2(n), &why);
+        return fail(NTT_ERR_MODULUS, "32-bit batched path needs an NTT-friendly modulus: " + why);
+    }
+    return run_host_sharded<uint32_t>(a, b, ab, n, batch, n_gpus,
+        [&](Device* dev, const uint32_t* da, const uint32_t* db, uint32_t* dout, size_t shard) {
+            return product_device<uint32_t, uint32_t>(dev, da, db, dout, n, p, shard, (size_t)n, (size_t)n,
+                                                      (size_t)(2 * n - 1), nullptr, 0, dev->stream);
+        });
+}
+
+int ntt_poly_multiply_batched_u64(const uint64_t* a, const uint64_t* b, uint64_t* ab, int n, uint64_t p, size_t batch, int n_gpus) {
+    int rc = check_args(a, b, ab, n, batch);
+    if (rc != NTT_OK) return rc;
+    const bool direct = direct_path_ok(p, transform_log2(n));
+    if (!direct && !crt_bound_ok(n, p))
+        return fail(NTT_ERR_MODULUS, "n*(p-1)^2 exceeds the product of the four CRT primes: result would not be exact");
+    return run_host_sharded<uint64_t>(a, b, ab, n, batch, n_gpus,
+        [&](Device* dev, const uint64_t* da, const uint64_t* db, uint64_t* dout, size_t shard) {
+            if (direct)
+                return product_device<uint64_t, uint64_t>(dev, da, db, dout, n, (uint32_t)p, shard, (size_t)n, (size_t)n,
+                                                          (size_t)(2 * n - 1), nullptr, 0, dev->stream);
+            return crt_product_device(dev, da, db, dout, n, p, shard, (size_t)n, (size_t)n, (size_t)(2 * n - 1), nullptr, 0,
+                                      dev->stream);
+        });
+}
+
+int ntt_poly_multiply_u64(const uint64_t* a, const uint64_t* b, uint64_t* ab, int n, uint64_t p) {
+    return ntt_poly_multiply_batched_u64(a, b, ab, n, p, 1, 1);
+}
+
+int ntt_poly_multiply_i32(const int* a, const int* b, int* ab, int n, int p) {
+    if (p < 2) return fail(NTT_ERR_ARG, "modulus must be positive");
+    int rc = check_args(a, b, ab, n, 1);
+    if (rc != NTT_OK) return rc;
+    if (direct_path_ok((uint64_t)p, transform_log2(n)))
+        return ntt_poly_multiply_batched((const uint32_t*)a, (const uint32_t*)b, (uint32_t*)ab, n, (uint32_t)p, 1, 1);
+    // not NTT-friendly: widen and take the CRT route
+    std::vector<uint64_t> wa(n), wb(n), wo(2 * (size_t)n - 1);
+    for (int i = 0; i < n; ++i) { wa[i] = (uint32_t)a[i]; wb[i] = (uint32_t)b[i]; }
+    rc = ntt_poly_multiply_batched_u64(wa.data(), wb.data(), wo.data(), n, (uint64_t)p, 1, 1);
+    if (rc != NTT_OK) return rc;
+    for (size_t i = 0; i < wo.size(); ++i) ab[i] = (int)wo[i];
+    return NTT_OK;
+}
+
+void poly_multiply(const int* a, const int* b, int* ab, int n, int p) {
+    if (ntt_poly_multiply_i32(a, b, ab, n, p) != NTT_OK) die("poly_multiply");
+}
+
+void poly_multiply_u64(const uint64_t* a, const uint64_t* b, uint64_t* ab, int n, uint64_t p) {
+    if (ntt_poly_multiply_u64(a, b, ab, n, p) != NTT_OK) die("poly_multiply_u64");
+}
+
+int ntt_profile_enable(int on) {
+    for (auto& r : g_prof) { hipError_t e = hipEventDestroy(r.e0); e = hipEventDestroy(r.e1); (void)e; }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return NTT_OK;
+}
+
+int ntt_profile_read(char* names, size_t names_len, double* total_ms, int* launches, int max_kernels) {
+    if (!names || !total_ms || !launches || max_kernels <= 0) return fail(NTT_ERR_ARG, "bad argument");
+    std::vector<std::string> labels;
+    std::string joined;
+    for (auto& r : g_prof) {
+        if (!r.e1) continue;
+        HIP_TRY(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.e0, r.e1));
+        size_t k = 0;
+        while (k < labels.size() && labels[k] != r.label) ++k;
+        if (k == labels.size()) {
+            if ((int)k >= max_kernels) continue;
+            labels.push_back(r.label); total_ms[k] = 0; launches[k] = 0;
+        }
+        total_ms[k] += ms; launches[k] += 1;
+    }
+    for (size_t k = 0; k < labels.size(); ++k) joined += (k ? "," : "") + labels[k];
+    snprintf(names, names_len, "%s", joined.c_str());
+    return (int)labels.size();
+}
+
+int ntt_describe_plan(int n, uint64_t p, char* buf, size_t buf_len) {
+    if (!buf || buf_len == 0 || n < 1) return fail(NTT_ERR_ARG, "bad argument");
+    const int logL = transform_log2(n);
+    std::string s;
+    const bool direct = direct_path_ok(p, logL);
+    const char* pipe = logL <= 12 ? "k_small" : logL == 13 ? "k_fused8192" : "k_fwd_strided,k_core_mul,k_inv_strided";
+    if (direct) s = pipe;
+    else s = std::string("4x(") + pipe + "),k_crt_merge";
+    snprintf(buf, buf_len, "%s", s.c_str());
+    return NTT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,398 @@
+// Device kernels of the polynomial-multiplication path (gfx950).
+//
+// A product of two length-n polynomials uses transform length L (power of two
+// >= 2n-1).  The spectrum is never materialised in natural order: the forward
+// transforms are decimation-in-frequency (natural in, digit-scrambled out),
+// the pointwise product is taken slot by slot, and the inverse transform is
+// the exact mirror (decimation-in-time), so the reference's bit-reversal
+// permutation (main_naive.cc:82-95) disappears while the outputs stay
+// identical (canonical residues of the same product).
+//
+//   L <= 4096        k_small       one workgroup per product, radix-2 stages in LDS
+//   L == 8192        k_fused8192   one workgroup per product: outer radix-2 stage in
+//                                  registers + two 4096-point LDS-resident cores
+//   L == 4096 * 2^Q  k_fwd_strided (radix-2^Q columns in registers, twiddle, store)
+//     (Q = 2..6)     k_core_mul    (4096-point forward of A and B, pointwise product,
+//                                   4096-point inverse, all in one workgroup)
+//                    k_inv_strided (twiddle, radix-2^Q inverse columns, canonical store)
+//   p > 2^32         the same pipeline once per CRT prime on 64-bit inputs, then k_crt_merge
+//
+// Reference loops these replace: zero-pad/copy main_naive.cc:147-153, butterfly
+// stages :106-128, pointwise product :163-165, n^-1 scaling :131-136, copy-out
+// :171-173, residue step :206-209, CRT merge :216-223.
+#pragma once
+#include "ntt_field.h"
+
+namespace nttamd {
+
+constexpr int CORE_N = 4096;   // points per LDS-resident core transform
+constexpr int CORE_T = 256;    // threads per core workgroup (16 points each)
+
+// ---------------------------------------------------------------------------
+// loads / stores with on-the-fly width conversion
+// ---------------------------------------------------------------------------
+template <bool LZ>
+__device__ __forceinline__ uint32_t load_coeff(const uint32_t* src, size_t idx, const Field<LZ>&, const FieldConsts&) {
+    return src[idx];
+}
+template <bool LZ>
+__device__ __forceinline__ uint32_t load_coeff(const uint64_t* src, size_t idx, const Field<LZ>& f, const FieldConsts& fc) {
+    return f.reduce64(src[idx], fc.r1, fc.r2);
+}
+
+__device__ __forceinline__ void load_tw16(uint32_t (&tw)[16], const uint32_t* base, int row) {
+    const uint4* q = reinterpret_cast<const uint4*>(base) + (size_t)row * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint4 v = q[k];
+        tw[4 * k + 0] = v.x; tw[4 * k + 1] = v.y; tw[4 * k + 2] = v.z; tw[4 * k + 3] = v.w;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 4096-point core.  Element e = d2*256 + d1*16 + d0 (base-16 digits).
+//   round 1: thread (d1,d0) holds the 16 values over d2      (stride 256)
+//   round 2: thread (d2,d0) holds the 16 values over d1      (stride 16)
+//   round 3: thread (d2,d1) holds the 16 values over d0      (contiguous)
+// LDS slot of (d2,d1,d0) is swizzled so that all three access patterns hit 32
+// distinct banks per half-wave.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int core_slot(int d2, int d1, int d0) {
+    return (d2 << 8) | ((d1 ^ (d2 & 1)) << 4) | (d0 ^ d1);
+}
+
+struct CoreTables {
+    const uint32_t* tw1F;  // [256][16]  Montgomery form of w4096^( t * bitrev4(pos))
+    const uint32_t* tw2F;  // [16][16]   Montgomery form of w256^ ( c * bitrev4(pos))
+    const uint32_t* tw1I;  // [256][16]  Montgomery form of w4096^(-t * bitrev4(pos)) * scale
+    const uint32_t* tw2I;  // [16][16]   Montgomery form of w256^ (-c * bitrev4(pos))
+};
+
+// Forward transform of two arrays at once.  In: a[i], b[i] = element t + 256*i, values in [0,B).
+// Out: a[i], b[i] = spectrum slot (d2 = t>>4, d1 = t&15, d0 = i), values in [0,B).
+template <bool LZ>
+__device__ __forceinline__ void core_forward2(uint32_t (&a)[16], uint32_t (&b)[16], uint32_t* ldsA, uint32_t* ldsB,
+                                              const Field<LZ>& f, const FieldConsts& fc, const CoreTables& tb, int t) {
+    uint32_t tw[16];
+    const int hi = t >> 4, lo = t & 15;
+    // round 1
+    dif_reg<4, LZ>(a, f, fc.rootF);
+    dif_reg<4, LZ>(b, f, fc.rootF);
+    load_tw16(tw, tb.tw1F, t);
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) {
+        if (pos) { a[pos] = f.mulw(a[pos], tw[pos]); b[pos] = f.mulw(b[pos], tw[pos]); }
+        const int s = core_slot(pos, hi, lo);
+        ldsA[s] = a[pos]; ldsB[s] = b[pos];
+    }
+    __syncthreads();
+    // round 2
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int s = core_slot(hi, i, lo); a[i] = ldsA[s]; b[i] = ldsB[s]; }
+    dif_reg<4, LZ>(a, f, fc.rootF);
+    dif_reg<4, LZ>(b, f, fc.rootF);
+    load_tw16(tw, tb.tw2F, lo);
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) {
+        if (pos) { a[pos] = f.mulw(a[pos], tw[pos]); b[pos] = f.mulw(b[pos], tw[pos]); }
+        const int s = core_slot(hi, pos, lo);
+        ldsA[s] = a[pos]; ldsB[s] = b[pos];
+    }
+    __syncthreads();
+    // round 3
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int s = core_slot(hi, lo, i); a[i] = ldsA[s]; b[i] = ldsB[s]; }
+    dif_reg<4, LZ>(a, f, fc.rootF);
+    dif_reg<4, LZ>(b, f, fc.rootF);
+}
+
+// Pointwise product of the two spectra followed by the inverse transform (mirror of
+// core_forward2).  Out: a[i] = element t + 256*i of 4096 * scale * (cyclic product) * R^-1,
+// LZ: in [0,4p), !LZ: in [0,p).
+template <bool LZ>
+__device__ __forceinline__ void core_pointwise_inverse(uint32_t (&a)[16], const uint32_t (&b)[16], uint32_t* ldsA,
+                                                       const Field<LZ>& f, const FieldConsts& fc, const CoreTables& tb, int t) {
+    uint32_t tw[16];
+    const int hi = t >> 4, lo = t & 15;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = f.mulpw(a[i], b[i]);
+    // inverse of round 3 (same thread owns the same slots: no barrier before the write)
+    dit_reg<4, LZ, true>(a, f, fc.rootI);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ldsA[core_slot(hi, lo, i)] = a[i];
+    __syncthreads();
+    // inverse of round 2
+    load_tw16(tw, tb.tw2I, lo);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        uint32_t v = ldsA[core_slot(hi, i, lo)];
+        a[i] = i ? f.mulw(v, tw[i]) : (LZ ? csub(v, f.B) : v);
+    }
+    dit_reg<4, LZ, true>(a, f, fc.rootI);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ldsA[core_slot(hi, i, lo)] = a[i];
+    __syncthreads();
+    // inverse of round 1 (every slot is multiplied: position 0 carries the scale factor)
+    load_tw16(tw, tb.tw1I, t);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = f.mulw(ldsA[core_slot(i, hi, lo)], tw[i]);
+    dit_reg<4, LZ, true>(a, f, fc.rootI);
+}
+
+// ---------------------------------------------------------------------------
+// k_core_mul: middle kernel of the multi-pass path.  Block (product, k1) of tmpA/tmpB
+// (4096 values each) -> same block of tmpC.  tmpC may alias tmpA.
+// ---------------------------------------------------------------------------
+template <bool LZ>
+__global__ void __launch_bounds__(CORE_T) k_core_mul(const uint32_t* tmpA, const uint32_t* tmpB, uint32_t* tmpC,
+                                                     FieldConsts fc, CoreTables tb) {
+    __shared__ uint32_t lds[2 * CORE_N];
+    const Field<LZ> f(fc);
+    const int t = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * CORE_N + t;
+    uint32_t a[16], b[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a[i] = tmpA[base + 256 * i]; b[i] = tmpB[base + 256 * i]; }
+    core_forward2<LZ>(a, b, lds, lds + CORE_N, f, fc, tb, t);
+    core_pointwise_inverse<LZ>(a, b, lds, f, fc, tb, t);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tmpC[base + 256 * i] = a[i];
+}
+
+// ---------------------------------------------------------------------------
+// k_fwd_strided: first pass of a length Lb = C * 2^Q transform on every block of Lb
+// values: thread = column j, registers = the 2^Q rows j + C*r.  PADDED: the source row
+// has only n_valid < = Lb/2 values, the rest are implicit zeros that are never read.
+// Output slot pos*C + j holds (row-transform output bitrev_Q(pos)) * w_Lb^(j*bitrev_Q(pos)).
+// Twiddle table layout: [(pos>>2)][j][pos&3] so a thread's 4 consecutive positions are one
+// 16-byte load and neighbouring threads are contiguous.
+// Grid: x = (C/256) * rows, z = 2 (A and B).
+// ---------------------------------------------------------------------------
+template <int Q, bool LZ, bool PADDED, typename TIn>
+__global__ void __launch_bounds__(256) k_fwd_strided(const TIn* inA, const TIn* inB, size_t a_stride, size_t b_stride,
+                                                     int n_valid, uint32_t* outA, uint32_t* outB, int C,
+                                                     const uint32_t* T1, FieldConsts fc) {
+    constexpr int R = 1 << Q;
+    const Field<LZ> f(fc);
+    const int chunks = C >> 8;
+    const int j = (int)(blockIdx.x % chunks) * 256 + threadIdx.x;
+    const size_t row = blockIdx.x / chunks;
+    const TIn* src = (blockIdx.z ? inB + row * b_stride : inA + row * a_stride);
+    uint32_t* dst = (blockIdx.z ? outB : outA) + row * ((size_t)C << Q);
+    uint32_t x[R];
+#pragma unroll
+    for (int r = 0; r < (PADDED ? R / 2 : R); ++r) {
+        const int idx = j + C * r;
+        x[r] = (!PADDED || idx < n_valid) ? load_coeff<LZ>(src, (size_t)idx, f, fc) : 0u;
+    }
+    dif_reg<Q, LZ, PADDED>(x, f, fc.rootF);
+    const uint4* Tq = reinterpret_cast<const uint4*>(T1);
+#pragma unroll
+    for (int g = 0; g < R / 4; ++g) {
+        const uint4 w = Tq[(size_t)g * C + j];
+        if (g) x[4 * g] = f.mulw(x[4 * g], w.x);
+        x[4 * g + 1] = f.mulw(x[4 * g + 1], w.y);
+        x[4 * g + 2] = f.mulw(x[4 * g + 2], w.z);
+        x[4 * g + 3] = f.mulw(x[4 * g + 3], w.w);
+    }
+#pragma unroll
+    for (int pos = 0; pos < R; ++pos) dst[(size_t)pos * C + j] = x[pos];
+}
+
+// ---------------------------------------------------------------------------
+// k_inv_strided: mirror of k_fwd_strided.  FINAL: results are reduced to [0,p) and only
+// indices < n_out are stored (row stride out_stride, type TOut); otherwise the block is
+// written back in place layout (uint32, lazy range).
+// ---------------------------------------------------------------------------
+template <int Q, bool LZ, bool FINAL, typename TOut>
+__global__ void __launch_bounds__(256) k_inv_strided(const uint32_t* in, TOut* out, size_t out_stride, int n_out, int C,
+                                                     const uint32_t* T3, FieldConsts fc) {
+    constexpr int R = 1 << Q;
+    const Field<LZ> f(fc);
+    const int chunks = C >> 8;
+    const int j = (int)(blockIdx.x % chunks) * 256 + threadIdx.x;
+    const size_t row = blockIdx.x / chunks;
+    const uint32_t* src = in + row * ((size_t)C << Q);
+    uint32_t x[R];
+    const uint4* Tq = reinterpret_cast<const uint4*>(T3);
+#pragma unroll
+    for (int g = 0; g < R / 4; ++g) {
+        const uint4 w = Tq[(size_t)g * C + j];
+        const uint32_t v0 = src[(size_t)(4 * g) * C + j];
+        x[4 * g] = g ? f.mulw(v0, w.x) : (LZ ? csub(v0, f.B) : v0);
+        x[4 * g + 1] = f.mulw(src[(size_t)(4 * g + 1) * C + j], w.y);
+        x[4 * g + 2] = f.mulw(src[(size_t)(4 * g + 2) * C + j], w.z);
+        x[4 * g + 3] = f.mulw(src[(size_t)(4 * g + 3) * C + j], w.w);
+    }
+    dit_reg<Q, LZ, true>(x, f, fc.rootI);
+    TOut* dst = out + row * out_stride;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int idx = j + C * r;
+        if (FINAL) {
+            if (idx < n_out) dst[idx] = (TOut)f.canon_inv(x[r]);
+        } else {
+            dst[idx] = (TOut)x[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_fused8192: whole product for L = 8192 (n <= 4096) in one workgroup.  The zero-padded
+// outer radix-2 stage splits the transform into an "even" 4096-point problem on x[j] and an
+// "odd" one on x[j] * w8192^j; both run through the core, and the last inverse stage
+// recombines them in registers.  ow = [owF[4096] | owI[4096]] Montgomery forms of w8192^(+-j).
+// ---------------------------------------------------------------------------
+template <bool LZ, typename TIn, typename TOut>
+__global__ void __launch_bounds__(CORE_T) k_fused8192(const TIn* A, const TIn* Bp, TOut* out, size_t a_stride,
+                                                      size_t b_stride, size_t out_stride, int n, int n_out,
+                                                      const uint32_t* ow, FieldConsts fc, CoreTables tb) {
+    __shared__ uint32_t lds[2 * CORE_N];
+    const Field<LZ> f(fc);
+    const int t = threadIdx.x;
+    const TIn* sa = A + (size_t)blockIdx.x * a_stride;
+    const TIn* sb = Bp + (size_t)blockIdx.x * b_stride;
+    uint32_t a[16], b[16], ev[16];
+    // even half
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = t + 256 * i;
+        a[i] = idx < n ? load_coeff<LZ>(sa, (size_t)idx, f, fc) : 0u;
+        b[i] = idx < n ? load_coeff<LZ>(sb, (size_t)idx, f, fc) : 0u;
+    }
+    core_forward2<LZ>(a, b, lds, lds + CORE_N, f, fc, tb, t);
+    core_pointwise_inverse<LZ>(a, b, lds, f, fc, tb, t);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ev[i] = a[i];
+    __syncthreads();  // the odd half reuses the LDS the even half may still be reading
+    // odd half
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = t + 256 * i;
+        const uint32_t w = ow[idx];
+        a[i] = idx < n ? f.mulw(load_coeff<LZ>(sa, (size_t)idx, f, fc), w) : 0u;
+        b[i] = idx < n ? f.mulw(load_coeff<LZ>(sb, (size_t)idx, f, fc), w) : 0u;
+    }
+    core_forward2<LZ>(a, b, lds, lds + CORE_N, f, fc, tb, t);
+    core_pointwise_inverse<LZ>(a, b, lds, f, fc, tb, t);
+    TOut* dst = out + (size_t)blockIdx.x * out_stride;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = t + 256 * i;
+        uint32_t x = ev[i], y = a[i];
+        f.dit(x, y, ow[CORE_N + idx]);
+        if (idx < n_out) dst[idx] = (TOut)f.canon_inv(x);
+        if (idx + CORE_N < n_out) dst[idx + CORE_N] = (TOut)f.canon_inv(y);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_small: any L = 2^logL <= 4096, one workgroup per product, radix-2 stages in LDS with a
+// barrier per stage.  twF/twI = Montgomery forms of wL^(+-e), e < L/2; scale_m = Montgomery
+// form of L^-1 * R.
+// ---------------------------------------------------------------------------
+template <bool LZ, typename TIn, typename TOut>
+__global__ void __launch_bounds__(256) k_small(const TIn* A, const TIn* Bp, TOut* out, size_t a_stride, size_t b_stride,
+                                               size_t out_stride, int n, int n_out, int logL, const uint32_t* twF,
+                                               const uint32_t* twI, uint32_t scale_m, FieldConsts fc) {
+    __shared__ uint32_t la[CORE_N];
+    __shared__ uint32_t lb[CORE_N];
+    const Field<LZ> f(fc);
+    const int L = 1 << logL, half = L >> 1;
+    const int t = threadIdx.x, T = blockDim.x;
+    const TIn* sa = A + (size_t)blockIdx.x * a_stride;
+    const TIn* sb = Bp + (size_t)blockIdx.x * b_stride;
+    for (int i = t; i < L; i += T) {
+        la[i] = i < n ? load_coeff<LZ>(sa, (size_t)i, f, fc) : 0u;
+        lb[i] = i < n ? load_coeff<LZ>(sb, (size_t)i, f, fc) : 0u;
+    }
+    __syncthreads();
+    for (int s = 0; s < logL; ++s) {
+        const int h = half >> s;
+        for (int k = t; k < half; k += T) {
+            const int j = k & (h - 1);
+            const int i = ((k - j) << 1) + j;
+            const uint32_t w = twF[j << s];
+            f.dif(la[i], la[i + h], w);
+            f.dif(lb[i], lb[i + h], w);
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < L; i += T) la[i] = f.mulpw(la[i], lb[i]);
+    __syncthreads();
+    for (int s = logL - 1; s >= 0; --s) {
+        const int h = half >> s;
+        for (int k = t; k < half; k += T) {
+            const int j = k & (h - 1);
+            const int i = ((k - j) << 1) + j;
+            f.dit(la[i], la[i + h], twI[j << s]);
+        }
+        __syncthreads();
+    }
+    TOut* dst = out + (size_t)blockIdx.x * out_stride;
+    for (int i = t; i < n_out; i += T) dst[i] = (TOut)f.canon_fwd(f.mulw(la[i], scale_m));
+}
+
+// ---------------------------------------------------------------------------
+// k_crt_merge: 128-bit CRT recombination, one thread per coefficient.
+//   S = sum_i M_i * ((r_i * M_i^-1) mod p_i);  S mod M;  then mod p.
+// Same value as the reference loop (main_naive.cc:216-223, main_mpi_CRT.cc:512-522): the sum
+// of four terms < M is brought below M by subtracting 2M and M conditionally instead of a
+// 128-bit division, and the final "mod p" uses a reciprocal-based 128-by-64 remainder.
+// ---------------------------------------------------------------------------
+struct CrtConsts {
+    uint32_t q[4];        // the four NTT primes
+    uint32_t nq[4];       // -q^-1 mod 2^32
+    uint32_t minv_m[4];   // Montgomery form of (M/q_i)^-1 mod q_i
+    uint64_t mi_lo[4];    // M/q_i, low 64 bits
+    uint32_t mi_hi[4];    // M/q_i, bits 64..95
+    uint64_t M_lo, M_hi;  // M = product of the four primes (< 2^120)
+    uint64_t p;           // final modulus
+    uint64_t d;           // p << shift (top bit set)
+    uint64_t v;           // floor((2^128-1)/d) - 2^64
+    int shift;
+};
+
+// (u1:u0) mod (d >> shift) for u1 < (d >> shift); d normalised (Moeller-Granlund 2-by-1 division)
+__device__ __forceinline__ uint64_t rem_2by1(uint64_t u1, uint64_t u0, uint64_t d, uint64_t v, int shift) {
+    if (shift) { u1 = (u1 << shift) | (u0 >> (64 - shift)); u0 <<= shift; }
+    uint64_t q0 = v * u1, q1 = __umul64hi(v, u1);
+    q0 += u0;
+    q1 += u1 + (q0 < u0 ? 1u : 0u);
+    q1 += 1;
+    uint64_t r = u0 - q1 * d;
+    if (r > q0) r += d;
+    if (r >= d) r -= d;
+    return r >> shift;
+}
+
+__global__ void __launch_bounds__(256) k_crt_merge(const uint32_t* res, size_t res_stride, uint64_t* out, size_t count,
+                                                   size_t rows, size_t out_stride, size_t row_stride, CrtConsts c) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = blockIdx.y;
+    if (i >= count || row >= rows) return;
+    uint64_t s_lo = 0, s_hi = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t r = res[(size_t)k * res_stride + row * row_stride + i];
+        const uint32_t t = csub(redc_lazy((uint64_t)r * c.minv_m[k], c.q[k], c.nq[k]), c.q[k]);
+        const uint64_t lo = c.mi_lo[k] * t;
+        const uint64_t hi = __umul64hi(c.mi_lo[k], (uint64_t)t) + (uint64_t)c.mi_hi[k] * t;
+        s_lo += lo;
+        s_hi += hi + (s_lo < lo ? 1u : 0u);
+    }
+    // S < 4M: subtract 2M, then M, when possible
+    const uint64_t m2_lo = c.M_lo << 1, m2_hi = (c.M_hi << 1) | (c.M_lo >> 63);
+    if (s_hi > m2_hi || (s_hi == m2_hi && s_lo >= m2_lo)) {
+        const uint64_t b = s_lo < m2_lo ? 1u : 0u;
+        s_lo -= m2_lo; s_hi -= m2_hi + b;
+    }
+    if (s_hi > c.M_hi || (s_hi == c.M_hi && s_lo >= c.M_lo)) {
+        const uint64_t b = s_lo < c.M_lo ? 1u : 0u;
+        s_lo -= c.M_lo; s_hi -= c.M_hi + b;
+    }
+    const uint64_t r1 = rem_2by1(0, s_hi, c.d, c.v, c.shift);
+    out[row * out_stride + i] = rem_2by1(r1, s_lo, c.d, c.v, c.shift);
+}
+
+}  // namespace nttamd

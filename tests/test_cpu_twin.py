@@ -1,0 +1,89 @@
+"""Host logic and kernel index arithmetic without a GPU: the library sources compiled by g++ over a
+HIP stand-in (tests/cpu_twin) must reproduce the oracle bit for bit.  This exercises plan building,
+dispatch by size and modulus, twiddle tables, the LDS slot mapping, the lazy-range bounds and the
+128-bit CRT merge -- everything except the GPU code generation itself (covered by the -m gpu tests)."""
+import numpy as np
+import pytest
+
+from golden_util import iter_golden
+
+BIGP = 1337006139375617
+
+
+@pytest.mark.parametrize("p", [7340033, 104857601, 469762049, 998244353, 1004535809, 1224736769])
+def test_direct_path_all_size_classes(twin, oracle, p):
+    rng = np.random.default_rng(p % 97)
+    for n in (1, 2, 4, 8, 64, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072):
+        a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
+        assert np.array_equal(twin.multiply_u64(a, b, p), oracle.ntt_multiply(a, b, p)), n
+
+
+def test_golden_vectors(twin):
+    for name, n, p, a, b, out in iter_golden():
+        assert np.array_equal(twin.multiply_u64(a, b, p), out), name
+
+
+def test_extreme_values_exercise_lazy_bounds(twin, oracle):
+    for p in (998244353, 1004535809, 1224736769, 7340033):
+        for n in (4096, 8192, 131072):
+            a = np.full(n, p - 1, dtype=np.uint64)
+            assert np.array_equal(twin.multiply_u64(a, a, p), oracle.ntt_multiply(a, a, p)), (p, n)
+
+
+def test_crt_path(twin, oracle):
+    rng = np.random.default_rng(4)
+    for n in (1, 4, 1000, 4096, 8192, 131072):
+        a = rng.integers(0, BIGP, n, dtype=np.uint64); b = rng.integers(0, BIGP, n, dtype=np.uint64)
+        want = oracle.crt_ntt_multiply(a, b, BIGP) if n & (n - 1) == 0 else oracle.schoolbook_u64(a, b, BIGP)
+        assert np.array_equal(twin.multiply_u64(a, b, BIGP), want), n
+    a = np.full(131072, BIGP - 1, dtype=np.uint64)
+    assert np.array_equal(twin.multiply_u64(a, a, BIGP), oracle.crt_ntt_multiply(a, a, BIGP))
+
+
+@pytest.mark.parametrize("p,n", [(1000000007, 100), (97, 50), (2**31 - 1, 64), (4294967291, 16), (2**40 + 15, 300),
+                                 (2**58 - 27, 4), (2, 10), (2**59 - 55, 1)])
+def test_arbitrary_moduli_through_crt(twin, oracle, p, n):
+    rng = np.random.default_rng(6)
+    a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
+    assert np.array_equal(twin.multiply_u64(a, b, p), oracle.schoolbook_u64(a, b, p))
+
+
+def test_non_power_of_two_lengths(twin, oracle):
+    p = 998244353
+    rng = np.random.default_rng(7)
+    for n in (3, 5, 100, 1000, 3000, 4097, 5000, 9000, 100000):
+        a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
+        m = 1 << (n - 1).bit_length()
+        az = np.zeros(m, dtype=np.uint64); bz = np.zeros(m, dtype=np.uint64); az[:n] = a; bz[:n] = b
+        assert np.array_equal(twin.multiply_u64(a, b, p), oracle.ntt_multiply(az, bz, p)[:2 * n - 1]), n
+
+
+def test_batched_and_i32_entry_points(twin, oracle):
+    p = 998244353
+    rng = np.random.default_rng(8)
+    for n, batch in ((4096, 5), (1024, 9), (16384, 3)):
+        a = rng.integers(0, p, (batch, n), dtype=np.uint32); b = rng.integers(0, p, (batch, n), dtype=np.uint32)
+        got = twin.multiply_batched(a, b, p)
+        for r in range(batch):
+            assert np.array_equal(got[r].astype(np.uint64), oracle.ntt_multiply(a[r], b[r], p))
+    a = rng.integers(0, BIGP, (3, 2048), dtype=np.uint64); b = rng.integers(0, BIGP, (3, 2048), dtype=np.uint64)
+    got = twin.multiply_batched_u64(a, b, BIGP)
+    for r in range(3):
+        assert np.array_equal(got[r], oracle.crt_ntt_multiply(a[r], b[r], BIGP))
+    assert twin.multiply_i32(np.array([4, 1, 5, 2]), np.array([1, 5, 5, 4]), 7340033).tolist() == [4, 21, 30, 48, 39, 30, 8]
+    a = rng.integers(0, 1000000007, 40, dtype=np.int32); b = rng.integers(0, 1000000007, 40, dtype=np.int32)
+    assert np.array_equal(twin.multiply_i32(a, b, 1000000007), oracle.schoolbook_i32(a, b, 1000000007))
+
+
+def test_error_reporting(twin):
+    from ntt_amd._binding import NttError
+    big = np.ones(1 << 19, dtype=np.uint64)
+    with pytest.raises(NttError) as e:
+        twin.multiply_u64(big, big, BIGP)
+    assert e.value.status == -2
+    with pytest.raises(NttError):
+        twin.multiply_batched(np.ones((2, 8), dtype=np.uint32), np.ones((2, 8), dtype=np.uint32), 1000000007)
+    assert twin.describe_plan(131072, 998244353) == "k_fwd_strided,k_core_mul,k_inv_strided"
+    assert twin.describe_plan(4096, 998244353) == "k_fused8192"
+    assert twin.describe_plan(4, BIGP).endswith("k_crt_merge")
+    assert twin.lib.ntt_workspace_bytes(131072, 998244353, 4) == 2 * 4 * (1 << 18) * 4

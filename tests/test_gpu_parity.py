@@ -1,0 +1,159 @@
+"""GPU parity: the HIP library, called through its C ABI, against the CPU oracle on the same
+seeded inputs -- bit-exact (integer arithmetic)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PRIMES32 = [7340033, 104857601, 469762049, 998244353, 1004535809, 1224736769]
+BIGP = 1337006139375617
+
+
+def rand(rng, p, shape):
+    return rng.integers(0, p, shape, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("p", PRIMES32)
+@pytest.mark.parametrize("n", [1, 2, 4, 16, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072])
+def test_direct_path_matches_oracle(gpu_lib, oracle, p, n):
+    rng = np.random.default_rng(n * 7 + p % 1000)
+    a, b = rand(rng, p, n), rand(rng, p, n)
+    assert np.array_equal(gpu_lib.multiply_u64(a, b, p), oracle.ntt_multiply(a, b, p))
+
+
+@pytest.mark.parametrize("n", [3, 5, 100, 1000, 3000, 4097, 5000, 100000])
+def test_non_power_of_two_lengths(gpu_lib, oracle, n):
+    # the reference needs n = 2^k; the oracle is fed the zero-extended operands instead
+    p = 998244353
+    rng = np.random.default_rng(n)
+    a, b = rand(rng, p, n), rand(rng, p, n)
+    m = 1 << (n - 1).bit_length()
+    az = np.zeros(m, dtype=np.uint64); bz = np.zeros(m, dtype=np.uint64)
+    az[:n] = a; bz[:n] = b
+    want = oracle.ntt_multiply(az, bz, p)[:2 * n - 1]
+    assert np.array_equal(gpu_lib.multiply_u64(a, b, p), want)
+
+
+@pytest.mark.parametrize("p", [7340033, 998244353, 1224736769])
+@pytest.mark.parametrize("n", [4, 4096, 131072])
+def test_extreme_values(gpu_lib, oracle, p, n):
+    # all coefficients p-1 (largest products), all zero, and a single one
+    a = np.full(n, p - 1, dtype=np.uint64)
+    assert np.array_equal(gpu_lib.multiply_u64(a, a, p), oracle.ntt_multiply(a, a, p))
+    z = np.zeros(n, dtype=np.uint64)
+    assert not gpu_lib.multiply_u64(a, z, p).any()
+    e = z.copy(); e[n - 1] = 1
+    got = gpu_lib.multiply_u64(a, e, p)
+    assert np.array_equal(got[n - 1:], a) and not got[:n - 1].any()
+
+
+@pytest.mark.parametrize("n", [1, 4, 1000, 4096, 8192, 131072])
+def test_crt_path_matches_oracle(gpu_lib, oracle, n):
+    rng = np.random.default_rng(n + 99)
+    a, b = rand(rng, BIGP, n), rand(rng, BIGP, n)
+    if n & (n - 1) == 0:
+        want = oracle.crt_ntt_multiply(a, b, BIGP)
+    else:
+        want = oracle.schoolbook_u64(a, b, BIGP)
+    assert np.array_equal(gpu_lib.multiply_u64(a, b, BIGP), want)
+
+
+def test_crt_path_extreme_values(gpu_lib, oracle):
+    n = 131072
+    a = np.full(n, BIGP - 1, dtype=np.uint64)
+    assert np.array_equal(gpu_lib.multiply_u64(a, a, BIGP), oracle.crt_ntt_multiply(a, a, BIGP))
+
+
+@pytest.mark.parametrize("p,n", [(1000000007, 100), (97, 50), (2**31 - 1, 64), (4294967291, 16), (2**40 + 15, 2048)])
+def test_unfriendly_moduli_take_the_crt_route(gpu_lib, oracle, p, n):
+    rng = np.random.default_rng(5)
+    a, b = rand(rng, p, n), rand(rng, p, n)
+    assert np.array_equal(gpu_lib.multiply_u64(a, b, p), oracle.schoolbook_u64(a, b, p))
+
+
+def test_i32_entry_point(gpu_lib, oracle):
+    a = np.array([4, 1, 5, 2], dtype=np.int32); b = np.array([1, 5, 5, 4], dtype=np.int32)
+    got = gpu_lib.multiply_i32(a, b, 7340033)
+    assert got.tolist() == [4, 21, 30, 48, 39, 30, 8]          # nttdata/0.out
+    assert np.array_equal(got, oracle.schoolbook_i32(a, b, 7340033))
+    rng = np.random.default_rng(3)
+    p = 998244353
+    a = rng.integers(0, p, 512, dtype=np.int32); b = rng.integers(0, p, 512, dtype=np.int32)
+    assert np.array_equal(gpu_lib.multiply_i32(a, b, p), oracle.schoolbook_i32(a, b, p))
+
+
+@pytest.mark.parametrize("n,batch", [(4096, 64), (131072, 6), (1024, 33), (16384, 5)])
+def test_batched_rows_are_independent_products(gpu_lib, oracle, n, batch):
+    p = 998244353
+    rng = np.random.default_rng(batch)
+    a = rng.integers(0, p, (batch, n), dtype=np.uint32); b = rng.integers(0, p, (batch, n), dtype=np.uint32)
+    got = gpu_lib.multiply_batched(a, b, p)
+    for r in {0, 1, batch // 2, batch - 1}:
+        assert np.array_equal(got[r].astype(np.uint64), oracle.ntt_multiply(a[r], b[r], p)), r
+
+
+def test_batched_u64_crt(gpu_lib, oracle):
+    n, batch = 4096, 5
+    rng = np.random.default_rng(11)
+    a, b = rand(rng, BIGP, (batch, n)), rand(rng, BIGP, (batch, n))
+    got = gpu_lib.multiply_batched_u64(a, b, BIGP)
+    for r in range(batch):
+        assert np.array_equal(got[r], oracle.crt_ntt_multiply(a[r], b[r], BIGP)), r
+
+
+def test_golden_files(gpu_lib):
+    """Every committed golden vector: the reference's own data files (nttdata/0-3, filetest/0-3)
+    and outputs of the compiled reference on seeded inputs (p = 998244353, CRT path, CRT primes)."""
+    from golden_util import iter_golden
+    seen = 0
+    for name, n, p, a, b, out in iter_golden():
+        assert np.array_equal(gpu_lib.multiply_u64(a, b, p), out), name
+        seen += 1
+    assert seen >= 16
+
+
+def test_full_size_properties(gpu_lib):
+    """n = 2^17 batch: linearity (a*(b+c) = a*b + a*c) and commutativity, checked on every coefficient."""
+    p, n, batch = 998244353, 131072, 8
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, p, (batch, n), dtype=np.uint32)
+    b = rng.integers(0, p, (batch, n), dtype=np.uint32)
+    c = rng.integers(0, p, (batch, n), dtype=np.uint32)
+    bc = ((b.astype(np.uint64) + c) % p).astype(np.uint32)
+    ab = gpu_lib.multiply_batched(a, b, p).astype(np.uint64)
+    ac = gpu_lib.multiply_batched(a, c, p).astype(np.uint64)
+    abc = gpu_lib.multiply_batched(a, bc, p).astype(np.uint64)
+    assert np.array_equal(abc, (ab + ac) % p)
+    assert np.array_equal(gpu_lib.multiply_batched(b, a, p).astype(np.uint64), ab)
+    assert ab.max() < p
+
+
+def test_device_resident_entry_point_with_strides(gpu_lib, oracle):
+    import torch
+    p, n, batch = 998244353, 16384, 3
+    L = 2 * n
+    rng = np.random.default_rng(8)
+    a = rng.integers(0, p, (batch, n), dtype=np.int64); b = rng.integers(0, p, (batch, n), dtype=np.int64)
+    da = torch.zeros((batch, n + 64), dtype=torch.int32, device="cuda"); da[:, :n] = torch.from_numpy(a).to("cuda", torch.int32)
+    db = torch.from_numpy(b).to("cuda", torch.int32).contiguous()
+    out = torch.full((batch, L), -1, dtype=torch.int32, device="cuda")
+    st = gpu_lib.lib.ntt_poly_multiply_batched_device(da.data_ptr(), db.data_ptr(), out.data_ptr(), n, p, batch, n + 64, n, L,
+                                                      None, 0, torch.cuda.current_stream().cuda_stream)
+    gpu_lib.check(st)
+    torch.cuda.synchronize()
+    res = out.cpu().numpy()
+    for r in range(batch):
+        assert np.array_equal(res[r, :2 * n - 1].astype(np.uint64), oracle.ntt_multiply(a[r], b[r], p))
+        assert res[r, 2 * n - 1] == -1   # index 2n-1 is never written (main_naive.cc:171-173 copies 2n-1 values)
+
+
+def test_errors_are_reported_not_computed(gpu_lib):
+    from ntt_amd._binding import NttError
+    big = np.ones(1 << 19, dtype=np.uint64)
+    with pytest.raises(NttError):
+        gpu_lib.multiply_u64(big, big, BIGP)     # exceeds the CRT bound
+    with pytest.raises(NttError):
+        gpu_lib.multiply_batched(np.ones((2, 8), dtype=np.uint32), np.ones((2, 8), dtype=np.uint32), 1000000007)

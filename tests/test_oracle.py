@@ -1,0 +1,112 @@
+"""Pins the CPU oracle: against the reference's own data files, against the reference's own compiled
+functions (oracle/_ref, when present) and against independent arithmetic."""
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import iter_golden
+
+REF_TREE = "/root/reference"
+BIGP = 1337006139375617
+
+
+def test_oracle_reproduces_every_golden_vector(oracle):
+    seen = 0
+    for name, n, p, a, b, out in iter_golden():
+        assert np.array_equal(oracle.poly_multiply_u64(a, b, p), out), name
+        seen += 1
+    assert seen >= 16
+
+
+def test_hand_checkable_case(oracle):
+    # nttdata/0: (4,1,5,2)*(1,5,5,4) mod 7340033
+    assert oracle.ntt_multiply([4, 1, 5, 2], [1, 5, 5, 4], 7340033).tolist() == [4, 21, 30, 48, 39, 30, 8]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_TREE), reason="reference tree not mounted")
+def test_oracle_reads_reference_text_files_directly(oracle):
+    for i in range(4):
+        n, p, a, b = oracle.read_in(f"{REF_TREE}/nttdata/{i}.in")
+        ab = oracle.poly_multiply_u64(a, b, p)
+        assert oracle.check_out(f"{REF_TREE}/nttdata/{i}.out", ab, n) == 0
+        # files/<id>.out is what the reference programs wrote themselves
+        assert oracle.check_out(f"{REF_TREE}/files/{i}.out", ab, n) == 0
+
+
+def test_oracle_equals_compiled_reference(oracle, reference):
+    if not reference.available:
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(0)
+    for p in (7340033, 104857601, 469762049, 998244353, 1004535809, 1224736769):
+        for n in (1, 2, 8, 512, 4096):
+            a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
+            want = reference.ntt_multiply(a, b, p)
+            assert np.array_equal(oracle.ntt_multiply(a, b, p), want)
+            assert np.array_equal(oracle.ntt_multiply_openmp(a, b, p, 4), want)
+            if n >= 8:
+                assert np.array_equal(reference.openmp_ntt_multiply(a, b, p, 8), want)
+                assert np.array_equal(reference.barrett_ntt_multiply(a, b, p), want)
+    for n in (4, 256, 2048):
+        a = rng.integers(0, BIGP, n, dtype=np.uint64); b = rng.integers(0, BIGP, n, dtype=np.uint64)
+        want = reference.crt_ntt_multiply(a, b, BIGP)
+        assert np.array_equal(oracle.crt_ntt_multiply(a, b, BIGP), want)
+        assert np.array_equal(reference.openmp_crt_multiply(a, b, BIGP), want)
+
+
+def test_oracle_full_size_against_compiled_reference(oracle, reference):
+    if not reference.available:
+        pytest.skip("oracle/_ref not built")
+    n, p = 131072, 998244353
+    a = oracle.fill_random(n, p, 1); b = oracle.fill_random(n, p, 2)
+    assert np.array_equal(oracle.ntt_multiply(a, b, p), reference.ntt_multiply(a, b, p))
+    a = oracle.fill_random(n, BIGP, 3); b = oracle.fill_random(n, BIGP, 4)
+    assert np.array_equal(oracle.crt_ntt_multiply(a, b, BIGP), reference.crt_ntt_multiply(a, b, BIGP))
+
+
+def test_ntt_paths_equal_schoolbook(oracle):
+    rng = np.random.default_rng(1)
+    for p, n in ((998244353, 64), (7340033, 128), (BIGP, 64), (BIGP, 512)):
+        a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
+        assert np.array_equal(oracle.poly_multiply_u64(a, b, p), oracle.schoolbook_u64(a, b, p))
+    a = rng.integers(0, 7340033, 32, dtype=np.int32); b = rng.integers(0, 7340033, 32, dtype=np.int32)
+    assert np.array_equal(oracle.schoolbook_i32(a, b, 7340033).astype(np.uint64), oracle.ntt_multiply(a, b, 7340033))
+
+
+def test_forward_inverse_round_trip_and_convolution_theorem(oracle):
+    p, n = 998244353, 256
+    rng = np.random.default_rng(2)
+    x = rng.integers(0, p, n, dtype=np.uint64)
+    assert np.array_equal(oracle.ntt(oracle.ntt(x, False, p), True, p), x)
+    # X[k] = sum x[i] w^(ik) with w = 3^((p-1)/n)
+    w = pow(3, (p - 1) // n, p)
+    X = oracle.ntt(x, False, p)
+    for k in (0, 1, 5, n - 1):
+        assert int(X[k]) == sum(int(x[i]) * pow(w, i * k, p) for i in range(n)) % p
+
+
+def test_montgomery_and_barrett_known_answers(oracle):
+    L = oracle.lib
+    rng = np.random.default_rng(3)
+    for N in (7340033, 104857601, 469762049, 998244353):
+        for _ in range(200):
+            a, b = int(rng.integers(0, N)), int(rng.integers(0, N))
+            assert L.oracle_mont64fields_multiply(N, a, b) == a * b % N
+    for m in (7340033, 998244353, 1224736769):
+        for x in [0, 1, m - 1, m, m + 1, 2**62 - 1] + [int(v) for v in rng.integers(0, 2**62, 200, dtype=np.uint64)]:
+            assert L.oracle_barrett62_reduce(m, x) == x % m
+        for x in [2**64 - 1] + [int(v) for v in rng.integers(0, 2**64, 200, dtype=np.uint64)]:
+            assert L.oracle_barrett64_reduce(m, x) == x % m
+    assert L.oracle_pow(3, 998244352, 998244353) == 1
+    assert L.oracle_pow(3, 499122176, 998244353) == 998244352
+
+
+def test_harness_text_round_trip(oracle, tmp_path):
+    a = np.array([4, 1, 5, 2], dtype=np.uint64); b = np.array([1, 5, 5, 4], dtype=np.uint64)
+    ab = oracle.ntt_multiply(a, b, 7340033)
+    path = str(tmp_path / "0.out")
+    assert oracle.write_out(path, ab, 4) == 0
+    assert open(path).read() == "4\n21\n30\n48\n39\n30\n8\n"
+    assert oracle.check_out(path, ab, 4) == 0
+    ab[3] += 1
+    assert oracle.check_out(path, ab, 4) == 1
