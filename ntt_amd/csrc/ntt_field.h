@@ -144,7 +144,10 @@ NTT_HD constexpr int bitrev(int x, int bits) {
 // In-register radix-2^Q decimation-in-frequency transform: natural order in,
 // x[pos] = X[bitrev_Q(pos)] out.  rootF holds Montgomery forms of w64^e; the
 // 2^Q-th root is w64^(64 >> Q).  ZERO_UPPER: x[2^(Q-1)..] are known zeros.
-template <int Q, bool LZ, bool ZERO_UPPER = false>
+// LAZY_OUT: every output except x[0] is about to be multiplied by a twiddle
+// (mulw accepts any 32-bit value), so the last stage skips their reduction and
+// leaves them in [0, 2B).
+template <int Q, bool LZ, bool ZERO_UPPER = false, bool LAZY_OUT = false>
 NTT_HD void dif_reg(uint32_t (&x)[1 << Q], const Field<LZ>& f, const uint32_t (&rootF)[32]) {
     constexpr int N = 1 << Q;
 #pragma unroll
@@ -157,7 +160,13 @@ NTT_HD void dif_reg(uint32_t (&x)[1 << Q], const Field<LZ>& f, const uint32_t (&
                 if (ZERO_UPPER && s == 0) {
                     x[i + h] = (e == 0) ? x[i] : f.mulw(x[i], rootF[e]);
                 } else if (e == 0) {
-                    f.dif1(x[i], x[i + h]);
+                    if (LAZY_OUT && s == Q - 1) {
+                        const uint32_t u = x[i], v = x[i + h];
+                        x[i] = (i == 0) ? f.add(u, v) : u + v;
+                        x[i + h] = f.sub_raw(u, v);
+                    } else {
+                        f.dif1(x[i], x[i + h]);
+                    }
                 } else {
                     f.dif(x[i], x[i + h], rootF[e]);
                 }

@@ -25,6 +25,12 @@
 
 namespace nttamd {
 
+// Compiler-only barrier for memory operations: keeps loads issued before it ahead of the arithmetic
+// that follows and stores after it behind, which pins the software pipelining written below
+// (hipcc otherwise either hoists every load to the top, costing occupancy, or serialises
+// load -> wait -> use).  Emits no instruction.
+#define NTT_FENCE() asm volatile("" ::: "memory")
+
 constexpr int CORE_N = 4096;   // points per LDS-resident core transform
 constexpr int CORE_T = 256;    // threads per core workgroup (16 points each)
 
@@ -76,8 +82,8 @@ __device__ __forceinline__ void core_forward2(uint32_t (&a)[16], uint32_t (&b)[1
     uint32_t tw[16];
     const int hi = t >> 4, lo = t & 15;
     // round 1
-    dif_reg<4, LZ>(a, f, fc.rootF);
-    dif_reg<4, LZ>(b, f, fc.rootF);
+    dif_reg<4, LZ, false, true>(a, f, fc.rootF);
+    dif_reg<4, LZ, false, true>(b, f, fc.rootF);
     load_tw16(tw, tb.tw1F, t);
 #pragma unroll
     for (int pos = 0; pos < 16; ++pos) {
@@ -86,12 +92,12 @@ __device__ __forceinline__ void core_forward2(uint32_t (&a)[16], uint32_t (&b)[1
         ldsA[s] = a[pos]; ldsB[s] = b[pos];
     }
     __syncthreads();
+    load_tw16(tw, tb.tw2F, lo);
     // round 2
 #pragma unroll
     for (int i = 0; i < 16; ++i) { const int s = core_slot(hi, i, lo); a[i] = ldsA[s]; b[i] = ldsB[s]; }
-    dif_reg<4, LZ>(a, f, fc.rootF);
-    dif_reg<4, LZ>(b, f, fc.rootF);
-    load_tw16(tw, tb.tw2F, lo);
+    dif_reg<4, LZ, false, true>(a, f, fc.rootF);
+    dif_reg<4, LZ, false, true>(b, f, fc.rootF);
 #pragma unroll
     for (int pos = 0; pos < 16; ++pos) {
         if (pos) { a[pos] = f.mulw(a[pos], tw[pos]); b[pos] = f.mulw(b[pos], tw[pos]); }
@@ -120,9 +126,10 @@ __device__ __forceinline__ void core_pointwise_inverse(uint32_t (&a)[16], const 
     dit_reg<4, LZ, true>(a, f, fc.rootI);
 #pragma unroll
     for (int i = 0; i < 16; ++i) ldsA[core_slot(hi, lo, i)] = a[i];
+    NTT_FENCE();
+    load_tw16(tw, tb.tw2I, lo);  // next round's twiddles travel while the workgroup synchronises
     __syncthreads();
     // inverse of round 2
-    load_tw16(tw, tb.tw2I, lo);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         uint32_t v = ldsA[core_slot(hi, i, lo)];
@@ -131,9 +138,10 @@ __device__ __forceinline__ void core_pointwise_inverse(uint32_t (&a)[16], const 
     dit_reg<4, LZ, true>(a, f, fc.rootI);
 #pragma unroll
     for (int i = 0; i < 16; ++i) ldsA[core_slot(hi, i, lo)] = a[i];
-    __syncthreads();
-    // inverse of round 1 (every slot is multiplied: position 0 carries the scale factor)
+    NTT_FENCE();
     load_tw16(tw, tb.tw1I, t);
+    __syncthreads();
+    // inverse of round 1 (every slot is multiplied: the table carries the scale factor)
 #pragma unroll
     for (int i = 0; i < 16; ++i) a[i] = f.mulw(ldsA[core_slot(i, hi, lo)], tw[i]);
     dit_reg<4, LZ, true>(a, f, fc.rootI);
@@ -168,8 +176,8 @@ __global__ void __launch_bounds__(CORE_T) k_core_mul(const uint32_t* tmpA, const
 // 16-byte load and neighbouring threads are contiguous.
 // Grid: x = (C/256) * rows, z = 2 (A and B).
 // ---------------------------------------------------------------------------
-template <int Q, bool LZ, bool PADDED, typename TIn>
-__global__ void __launch_bounds__(256) k_fwd_strided(const TIn* inA, const TIn* inB, size_t a_stride, size_t b_stride,
+template <int Q, bool LZ, bool PADDED, bool FULL, int MINW, typename TIn>
+__global__ void __launch_bounds__(256, MINW) k_fwd_strided(const TIn* inA, const TIn* inB, size_t a_stride, size_t b_stride,
                                                      int n_valid, uint32_t* outA, uint32_t* outB, int C,
                                                      const uint32_t* T1, FieldConsts fc) {
     constexpr int R = 1 << Q;
@@ -180,23 +188,40 @@ __global__ void __launch_bounds__(256) k_fwd_strided(const TIn* inA, const TIn* 
     const TIn* src = (blockIdx.z ? inB + row * b_stride : inA + row * a_stride);
     uint32_t* dst = (blockIdx.z ? outB : outA) + row * ((size_t)C << Q);
     uint32_t x[R];
+    constexpr int G = R / 4;              // 16-byte twiddle groups (4 positions each)
+    constexpr int SG = G < 4 ? G : 4;     // groups per pipeline stage
+    constexpr int NS = G / SG;
+    const uint4* Tq = reinterpret_cast<const uint4*>(T1) + j;
+    uint4 wb[2][SG];
 #pragma unroll
     for (int r = 0; r < (PADDED ? R / 2 : R); ++r) {
         const int idx = j + C * r;
-        x[r] = (!PADDED || idx < n_valid) ? load_coeff<LZ>(src, (size_t)idx, f, fc) : 0u;
-    }
-    dif_reg<Q, LZ, PADDED>(x, f, fc.rootF);
-    const uint4* Tq = reinterpret_cast<const uint4*>(T1);
-#pragma unroll
-    for (int g = 0; g < R / 4; ++g) {
-        const uint4 w = Tq[(size_t)g * C + j];
-        if (g) x[4 * g] = f.mulw(x[4 * g], w.x);
-        x[4 * g + 1] = f.mulw(x[4 * g + 1], w.y);
-        x[4 * g + 2] = f.mulw(x[4 * g + 2], w.z);
-        x[4 * g + 3] = f.mulw(x[4 * g + 3], w.w);
+        x[r] = (!PADDED || FULL || idx < n_valid) ? load_coeff<LZ>(src, (size_t)idx, f, fc) : 0u;
     }
 #pragma unroll
-    for (int pos = 0; pos < R; ++pos) dst[(size_t)pos * C + j] = x[pos];
+    for (int k = 0; k < SG; ++k) wb[0][k] = Tq[(size_t)k * C];
+    NTT_FENCE();
+    dif_reg<Q, LZ, PADDED, true>(x, f, fc.rootF);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        if (st + 1 < NS) {
+#pragma unroll
+            for (int k = 0; k < SG; ++k) wb[(st + 1) & 1][k] = Tq[(size_t)((st + 1) * SG + k) * C];
+        }
+        NTT_FENCE();
+#pragma unroll
+        for (int k = 0; k < SG; ++k) {
+            const int g = st * SG + k;
+            const uint4 w = wb[st & 1][k];
+            if (g) x[4 * g] = f.mulw(x[4 * g], w.x);
+            x[4 * g + 1] = f.mulw(x[4 * g + 1], w.y);
+            x[4 * g + 2] = f.mulw(x[4 * g + 2], w.z);
+            x[4 * g + 3] = f.mulw(x[4 * g + 3], w.w);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[(size_t)(4 * g + q) * C + j] = x[4 * g + q];
+        }
+        NTT_FENCE();
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -204,8 +229,8 @@ __global__ void __launch_bounds__(256) k_fwd_strided(const TIn* inA, const TIn* 
 // indices < n_out are stored (row stride out_stride, type TOut); otherwise the block is
 // written back in place layout (uint32, lazy range).
 // ---------------------------------------------------------------------------
-template <int Q, bool LZ, bool FINAL, typename TOut>
-__global__ void __launch_bounds__(256) k_inv_strided(const uint32_t* in, TOut* out, size_t out_stride, int n_out, int C,
+template <int Q, bool LZ, bool FINAL, bool FULL, int MINW, typename TOut>
+__global__ void __launch_bounds__(256, MINW) k_inv_strided(const uint32_t* in, TOut* out, size_t out_stride, int n_out, int C,
                                                      const uint32_t* T3, FieldConsts fc) {
     constexpr int R = 1 << Q;
     const Field<LZ> f(fc);
@@ -214,15 +239,33 @@ __global__ void __launch_bounds__(256) k_inv_strided(const uint32_t* in, TOut* o
     const size_t row = blockIdx.x / chunks;
     const uint32_t* src = in + row * ((size_t)C << Q);
     uint32_t x[R];
-    const uint4* Tq = reinterpret_cast<const uint4*>(T3);
+    constexpr int G = R / 4;
+    constexpr int SG = G < 4 ? G : 4;
+    constexpr int NS = G / SG;
+    const uint4* Tq = reinterpret_cast<const uint4*>(T3) + j;
+    uint4 wb[2][SG];
 #pragma unroll
-    for (int g = 0; g < R / 4; ++g) {
-        const uint4 w = Tq[(size_t)g * C + j];
-        const uint32_t v0 = src[(size_t)(4 * g) * C + j];
-        x[4 * g] = g ? f.mulw(v0, w.x) : (LZ ? csub(v0, f.B) : v0);
-        x[4 * g + 1] = f.mulw(src[(size_t)(4 * g + 1) * C + j], w.y);
-        x[4 * g + 2] = f.mulw(src[(size_t)(4 * g + 2) * C + j], w.z);
-        x[4 * g + 3] = f.mulw(src[(size_t)(4 * g + 3) * C + j], w.w);
+    for (int k = 0; k < SG; ++k) wb[0][k] = Tq[(size_t)k * C];
+#pragma unroll
+    for (int pos = 0; pos < R; ++pos) x[pos] = src[(size_t)pos * C + j];
+    NTT_FENCE();
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        if (st + 1 < NS) {
+#pragma unroll
+            for (int k = 0; k < SG; ++k) wb[(st + 1) & 1][k] = Tq[(size_t)((st + 1) * SG + k) * C];
+        }
+        NTT_FENCE();
+#pragma unroll
+        for (int k = 0; k < SG; ++k) {
+            const int g = st * SG + k;
+            const uint4 w = wb[st & 1][k];
+            x[4 * g] = g ? f.mulw(x[4 * g], w.x) : (LZ ? csub(x[0], f.B) : x[0]);
+            x[4 * g + 1] = f.mulw(x[4 * g + 1], w.y);
+            x[4 * g + 2] = f.mulw(x[4 * g + 2], w.z);
+            x[4 * g + 3] = f.mulw(x[4 * g + 3], w.w);
+        }
+        NTT_FENCE();
     }
     dit_reg<Q, LZ, true>(x, f, fc.rootI);
     TOut* dst = out + row * out_stride;
@@ -230,7 +273,8 @@ __global__ void __launch_bounds__(256) k_inv_strided(const uint32_t* in, TOut* o
     for (int r = 0; r < R; ++r) {
         const int idx = j + C * r;
         if (FINAL) {
-            if (idx < n_out) dst[idx] = (TOut)f.canon_inv(x[r]);
+            // FULL: n_out = C*2^Q - 1, only the very last index is dropped
+            if ((FULL && r < R - 1) || idx < n_out) dst[idx] = (TOut)f.canon_inv(x[r]);
         } else {
             dst[idx] = (TOut)x[r];
         }

@@ -1,0 +1,96 @@
+"""N > 1 path on CPU: two gloo ranks shard a batch (and the CRT primes) the way bench.py / a
+multi-GPU caller does, each rank computing its shard with the CPU twin of the library; the
+gathered result must equal the oracle."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from ntt_amd.sharding import crt_prime_owner, shard_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from ntt_amd._binding import NttLibrary
+from ntt_amd.sharding import shard_range, crt_prime_owner, max_over_ranks, gather_rows
+from oracle_binding import Oracle
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib = NttLibrary(os.path.join(ROOT, "tests", "cpu_twin", "libnttamd_cputwin.so"))
+orc = Oracle()
+# 1. batched products, sharded by row
+p, n, batch = 998244353, 2048, 7
+rng = np.random.default_rng(123)           # same inputs on every rank
+a = rng.integers(0, p, (batch, n), dtype=np.uint32); b = rng.integers(0, p, (batch, n), dtype=np.uint32)
+lo, hi = shard_range(batch, rank, world)
+local = lib.multiply_batched(a[lo:hi], b[lo:hi], p)
+full = gather_rows(local, batch, dist)
+ok1 = all(np.array_equal(full[r].astype(np.uint64), orc.ntt_multiply(a[r], b[r], p)) for r in range(batch))
+# 2. CRT primes split across ranks, residues exchanged, every rank merges a coefficient slice
+P = 1337006139375617
+n2 = 1024
+A = rng.integers(0, P, n2, dtype=np.uint64); B = rng.integers(0, P, n2, dtype=np.uint64)
+primes = [lib.lib.ntt_crt_prime(i) for i in range(4)]
+res = np.zeros((4, 2 * n2 - 1), dtype=np.uint64)
+for i, q in enumerate(primes):
+    if crt_prime_owner(i, world) == rank:
+        res[i] = lib.multiply_u64(A % q, B % q, q)
+t = torch.from_numpy(res.astype(np.int64))
+dist.all_reduce(t)                           # disjoint rows: sum == exchange (cf. MPI_Bcast per prime)
+res = t.numpy().astype(np.uint64)
+M = 1
+for q in primes: M *= q
+lo2, hi2 = shard_range(2 * n2 - 1, rank, world)
+part = np.zeros(2 * n2 - 1, dtype=np.uint64)
+for j in range(lo2, hi2):
+    s = 0
+    for i, q in enumerate(primes):
+        Mi = M // q
+        s += Mi * ((int(res[i, j]) * pow(Mi % q, q - 2, q)) % q)
+    part[j] = (s % M) % P
+t2 = torch.from_numpy(part.astype(np.int64)); dist.all_reduce(t2)   # cf. MPI_Reduce(SUM) of disjoint slices
+ok2 = np.array_equal(t2.numpy().astype(np.uint64), orc.crt_ntt_multiply(A, B, P))
+slow = max_over_ranks(float(rank + 1), dist)
+if rank == 0:
+    print(json.dumps({"batched": bool(ok1), "crt": bool(ok2), "max": slow, "world": world}))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 256, 65536):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert [crt_prime_owner(i, 2) for i in range(4)] == [0, 1, 0, 1]
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def test_two_gloo_ranks_shard_batch_and_crt_primes(tmp_path):
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(f"ROOT = {ROOT!r}\n" + WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out == {"batched": True, "crt": True, "max": 2.0, "world": 2}

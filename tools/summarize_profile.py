@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Condenses a tools/profile_bench.sh output directory into the files kept under profiles/:
+  <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (library kernels only)
+  <tag>_pmc.json           per-kernel averages of every collected counter
+  traffic_<tag>.json       HBM bytes per launch per kernel, from FETCH_SIZE / WRITE_SIZE with the
+                           gfx950 corrections: both counters are in KiB; FETCH_SIZE tallies 128-byte
+                           requests of wide coalesced reads at 64 bytes, so it is doubled; WRITE_SIZE
+                           is exact.
+usage: tools/summarize_profile.py gpurun_out/prof_<tag> <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def short(name):
+    m = re.search(r"nttamd::(k_\w+)", name)
+    return m.group(1) if m else None
+
+
+def main(src, tag):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dst = os.path.join(root, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    if stats:
+        rows = list(csv.reader(open(stats[0])))
+        with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(rows[0])
+            for r in rows[1:]:
+                if short(r[0]):
+                    w.writerow(r)
+    pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            if k:
+                pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                pmc[k]["VGPR_Count"] = [float(r["VGPR_Count"])]
+                pmc[k]["LDS_Block_Size"] = [float(r["LDS_Block_Size"])]
+    summary = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in pmc.items()}
+    json.dump(summary, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+    traffic = {}
+    for k, d in summary.items():
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            rd, wr = d["FETCH_SIZE"] * 1024 * 2, d["WRITE_SIZE"] * 1024
+            traffic[k] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
+    json.dump(traffic, open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(traffic, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
