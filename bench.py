@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="products per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--lib", default=None, help="diagnostic: load this build of the library instead of the shipped one")
+    ap.add_argument("--no-verify", action="store_true", help="diagnostic: skip the oracle spot-check (ablated builds)")
     args = ap.parse_args()
 
     import numpy as np
@@ -89,7 +91,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n, p, B = args.n, args.p, args.batch
     L = 2 * n
-    lib = load_product_library()
+    if args.lib:
+        from ntt_amd._binding import NttLibrary
+        lib = NttLibrary(os.path.abspath(args.lib))
+    else:
+        lib = load_product_library()
     lib.init(0)
 
     gen = torch.Generator(device="cuda"); gen.manual_seed(0x5EED0000 + rank)
@@ -140,7 +146,7 @@ def main():
 
     # spot-check three products of this rank's batch against the oracle (outside the timed region)
     verified = None
-    if rank == 0:
+    if rank == 0 and not args.no_verify:
         from oracle_binding import Oracle
         orc = Oracle()
         res = out.cpu().numpy()

@@ -31,6 +31,15 @@ namespace nttamd {
 // load -> wait -> use).  Emits no instruction.
 #define NTT_FENCE() asm volatile("" ::: "memory")
 
+// Diagnostic builds only (tools/ablate.sh): -DNTT_ABLATE_BARRIER drops the workgroup barriers of the
+// core, -DNTT_ABLATE_GLOAD replaces its global data loads by register values.  Results are then
+// wrong by construction; only the timing is read.
+#ifdef NTT_ABLATE_BARRIER
+#define NTT_CORE_SYNC() NTT_FENCE()
+#else
+#define NTT_CORE_SYNC() __syncthreads()
+#endif
+
 constexpr int CORE_N = 4096;   // points per LDS-resident core transform
 constexpr int CORE_T = 256;    // threads per core workgroup (16 points each)
 
@@ -91,7 +100,7 @@ __device__ __forceinline__ void core_forward2(uint32_t (&a)[16], uint32_t (&b)[1
         const int s = core_slot(pos, hi, lo);
         ldsA[s] = a[pos]; ldsB[s] = b[pos];
     }
-    __syncthreads();
+    NTT_CORE_SYNC();
     load_tw16(tw, tb.tw2F, lo);
     // round 2
 #pragma unroll
@@ -104,7 +113,7 @@ __device__ __forceinline__ void core_forward2(uint32_t (&a)[16], uint32_t (&b)[1
         const int s = core_slot(hi, pos, lo);
         ldsA[s] = a[pos]; ldsB[s] = b[pos];
     }
-    __syncthreads();
+    NTT_CORE_SYNC();
     // round 3
 #pragma unroll
     for (int i = 0; i < 16; ++i) { const int s = core_slot(hi, lo, i); a[i] = ldsA[s]; b[i] = ldsB[s]; }
@@ -116,19 +125,23 @@ __device__ __forceinline__ void core_forward2(uint32_t (&a)[16], uint32_t (&b)[1
 // core_forward2).  Out: a[i] = element t + 256*i of 4096 * scale * (cyclic product) * R^-1,
 // LZ: in [0,4p), !LZ: in [0,p).
 template <bool LZ>
-__device__ __forceinline__ void core_pointwise_inverse(uint32_t (&a)[16], const uint32_t (&b)[16], uint32_t* ldsA,
-                                                       const Field<LZ>& f, const FieldConsts& fc, const CoreTables& tb, int t) {
-    uint32_t tw[16];
-    const int hi = t >> 4, lo = t & 15;
+__device__ __forceinline__ void core_pointwise(uint32_t (&a)[16], const uint32_t (&b)[16], const Field<LZ>& f) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) a[i] = f.mulpw(a[i], b[i]);
+}
+
+template <bool LZ>
+__device__ __forceinline__ void core_inverse(uint32_t (&a)[16], uint32_t* ldsA, const Field<LZ>& f, const FieldConsts& fc,
+                                             const CoreTables& tb, int t) {
+    uint32_t tw[16];
+    const int hi = t >> 4, lo = t & 15;
     // inverse of round 3 (same thread owns the same slots: no barrier before the write)
     dit_reg<4, LZ, true>(a, f, fc.rootI);
 #pragma unroll
     for (int i = 0; i < 16; ++i) ldsA[core_slot(hi, lo, i)] = a[i];
     NTT_FENCE();
     load_tw16(tw, tb.tw2I, lo);  // next round's twiddles travel while the workgroup synchronises
-    __syncthreads();
+    NTT_CORE_SYNC();
     // inverse of round 2
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -140,7 +153,7 @@ __device__ __forceinline__ void core_pointwise_inverse(uint32_t (&a)[16], const 
     for (int i = 0; i < 16; ++i) ldsA[core_slot(hi, i, lo)] = a[i];
     NTT_FENCE();
     load_tw16(tw, tb.tw1I, t);
-    __syncthreads();
+    NTT_CORE_SYNC();
     // inverse of round 1 (every slot is multiplied: the table carries the scale factor)
 #pragma unroll
     for (int i = 0; i < 16; ++i) a[i] = f.mulw(ldsA[core_slot(i, hi, lo)], tw[i]);
@@ -149,7 +162,8 @@ __device__ __forceinline__ void core_pointwise_inverse(uint32_t (&a)[16], const 
 
 // ---------------------------------------------------------------------------
 // k_core_mul: middle kernel of the multi-pass path.  Block (product, k1) of tmpA/tmpB
-// (4096 values each) -> same block of tmpC.  tmpC may alias tmpA.
+// (4096 values each) -> same block of tmpC.  tmpC may alias tmpA (a block is fully read before it
+// is written, and other blocks are other addresses).
 // ---------------------------------------------------------------------------
 template <bool LZ>
 __global__ void __launch_bounds__(CORE_T) k_core_mul(const uint32_t* tmpA, const uint32_t* tmpB, uint32_t* tmpC,
@@ -159,10 +173,15 @@ __global__ void __launch_bounds__(CORE_T) k_core_mul(const uint32_t* tmpA, const
     const int t = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * CORE_N + t;
     uint32_t a[16], b[16];
+#ifdef NTT_ABLATE_GLOAD
+    for (int i = 0; i < 16; ++i) { a[i] = (uint32_t)base * 2654435761u + i; b[i] = a[i] ^ 12345u; }
+#else
 #pragma unroll
     for (int i = 0; i < 16; ++i) { a[i] = tmpA[base + 256 * i]; b[i] = tmpB[base + 256 * i]; }
+#endif
     core_forward2<LZ>(a, b, lds, lds + CORE_N, f, fc, tb, t);
-    core_pointwise_inverse<LZ>(a, b, lds, f, fc, tb, t);
+    core_pointwise<LZ>(a, b, f);
+    core_inverse<LZ>(a, lds, f, fc, tb, t);
 #pragma unroll
     for (int i = 0; i < 16; ++i) tmpC[base + 256 * i] = a[i];
 }
@@ -305,7 +324,8 @@ __global__ void __launch_bounds__(CORE_T) k_fused8192(const TIn* A, const TIn* B
         b[i] = idx < n ? load_coeff<LZ>(sb, (size_t)idx, f, fc) : 0u;
     }
     core_forward2<LZ>(a, b, lds, lds + CORE_N, f, fc, tb, t);
-    core_pointwise_inverse<LZ>(a, b, lds, f, fc, tb, t);
+    core_pointwise<LZ>(a, b, f);
+    core_inverse<LZ>(a, lds, f, fc, tb, t);
 #pragma unroll
     for (int i = 0; i < 16; ++i) ev[i] = a[i];
     __syncthreads();  // the odd half reuses the LDS the even half may still be reading
@@ -318,7 +338,8 @@ __global__ void __launch_bounds__(CORE_T) k_fused8192(const TIn* A, const TIn* B
         b[i] = idx < n ? f.mulw(load_coeff<LZ>(sb, (size_t)idx, f, fc), w) : 0u;
     }
     core_forward2<LZ>(a, b, lds, lds + CORE_N, f, fc, tb, t);
-    core_pointwise_inverse<LZ>(a, b, lds, f, fc, tb, t);
+    core_pointwise<LZ>(a, b, f);
+    core_inverse<LZ>(a, lds, f, fc, tb, t);
     TOut* dst = out + (size_t)blockIdx.x * out_stride;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {

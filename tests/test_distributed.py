@@ -57,9 +57,16 @@ for j in range(lo2, hi2):
     part[j] = (s % M) % P
 t2 = torch.from_numpy(part.astype(np.int64)); dist.all_reduce(t2)   # cf. MPI_Reduce(SUM) of disjoint slices
 ok2 = np.array_equal(t2.numpy().astype(np.uint64), orc.crt_ntt_multiply(A, B, P))
+# 3. the packaged form of (2): primes over ranks through the per-prime / merge entry points of the C ABI
+from ntt_amd.distributed import crt_multiply_distributed
+A3 = rng.integers(0, P, (3, 4096), dtype=np.uint64); B3 = rng.integers(0, P, (3, 4096), dtype=np.uint64)
+got3 = crt_multiply_distributed(lib, A3, B3, P, dist, torch.device("cpu"))
+ok3 = all(np.array_equal(got3[r], orc.crt_ntt_multiply(A3[r], B3[r], P)) for r in range(3))
+got4 = crt_multiply_distributed(lib, A[:1000], B[:1000], P, dist, torch.device("cpu"))
+ok3 = ok3 and np.array_equal(got4, orc.schoolbook_u64(A[:1000], B[:1000], P))
 slow = max_over_ranks(float(rank + 1), dist)
 if rank == 0:
-    print(json.dumps({"batched": bool(ok1), "crt": bool(ok2), "max": slow, "world": world}))
+    print(json.dumps({"batched": bool(ok1), "crt": bool(ok2), "crt_packaged": bool(ok3), "max": slow, "world": world}))
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -93,4 +100,4 @@ def test_two_gloo_ranks_shard_batch_and_crt_primes(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out == {"batched": True, "crt": True, "max": 2.0, "world": 2}
+    assert out == {"batched": True, "crt": True, "crt_packaged": True, "max": 2.0, "world": 2}

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Timing of the non-headline configurations (device-resident operands), one JSON line each:
+  config3: 65536 x n=4096 products, p = 998244353 and 7340033 (single fused kernel per product)
+  config4: n=131072, p = 1337006139375617 through the four CRT primes + merge, batch 1 and 64
+  config2: single n=131072 product, p = 998244353, host pointers (end-to-end latency incl. PCIe)"""
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+from ntt_amd._binding import load_product_library
+from oracle_binding import Oracle
+
+lib = load_product_library(); lib.init(0)
+orc = Oracle()
+torch.cuda.set_device(0)
+stream = torch.cuda.current_stream().cuda_stream
+
+
+def timed(fn, warm=3, reps=10):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def config3(p, B=65536, n=4096):
+    gen = torch.Generator(device="cuda"); gen.manual_seed(0xC0FFEE00)
+    a = torch.randint(0, p, (B, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
+    b = torch.randint(0, p, (B, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
+    out = torch.zeros((B, 2 * n), dtype=torch.int32, device="cuda")
+    def step():
+        lib.check(lib.lib.ntt_poly_multiply_batched_device(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, p, B, n, n, 2 * n, None, 0, stream))
+    dt = timed(step)
+    res = out[:2].cpu().numpy(); ah = a[:2].cpu().numpy(); bh = b[:2].cpu().numpy()
+    ok = all(np.array_equal(res[r, :2 * n - 1].astype(np.uint64), orc.ntt_multiply(ah[r], bh[r], p)) for r in range(2))
+    print(json.dumps({"workload": f"config3 {B} x n={n} p={p}", "products_per_s": B / dt, "ms": dt * 1e3,
+                      "GBps_compulsory(16n)": B * 16 * n / dt / 1e9, "verified": ok}), flush=True)
+
+
+def config4(B, n=131072, p=1337006139375617):
+    rng = np.random.default_rng(0xB16B00B5)
+    ah = rng.integers(0, p, (B, n), dtype=np.uint64); bh = rng.integers(0, p, (B, n), dtype=np.uint64)
+    a = torch.from_numpy(ah.view(np.int64)).cuda(); b = torch.from_numpy(bh.view(np.int64)).cuda()
+    out = torch.zeros((B, 2 * n), dtype=torch.int64, device="cuda")
+    def step():
+        lib.check(lib.lib.ntt_poly_multiply_batched_device_u64(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, p, B, n, n, 2 * n, None, 0, stream))
+    dt = timed(step)
+    res = out[0].cpu().numpy().view(np.uint64)
+    ok = np.array_equal(res[:2 * n - 1], orc.crt_ntt_multiply(ah[0], bh[0], p))
+    print(json.dumps({"workload": f"config4 CRT batch {B} n={n} p={p}", "products_per_s": B / dt, "ms": dt * 1e3,
+                      "GBps_model(480n)": B * 480 * n / dt / 1e9, "verified": bool(ok)}), flush=True)
+
+
+def config2(n=131072, p=998244353):
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
+    lib.multiply_u64(a, b, p)
+    t0 = time.perf_counter(); reps = 20
+    for _ in range(reps): got = lib.multiply_u64(a, b, p)
+    dt = (time.perf_counter() - t0) / reps
+    print(json.dumps({"workload": f"config2 single n={n} p={p} host pointers (H2D + kernels + D2H)", "ms": dt * 1e3,
+                      "verified": bool(np.array_equal(got, orc.ntt_multiply(a, b, p)))}), flush=True)
+
+
+if __name__ == "__main__":
+    config2()
+    config3(998244353); config3(7340033)
+    config4(1); config4(64)
