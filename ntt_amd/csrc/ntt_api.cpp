@@ -175,11 +175,6 @@ size_t pipeline_workspace_bytes(int logL, size_t batch) {
     return 2 * batch * ((size_t)1 << logL) * sizeof(uint32_t);
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-
 template <int Q, bool LZ, bool FULL, int MINW, typename TIn, typename TOut>
 void launch_multipass_v(const Plan& pl, const TIn* a, const TIn* b, TOut* out, int n, size_t batch, size_t sa, size_t sb,
                         size_t so, uint32_t* tmpA, uint32_t* tmpB, hipStream_t st) {
@@ -197,17 +192,9 @@ template <int Q, bool LZ, typename TIn, typename TOut>
 void launch_multipass(const Plan& pl, const TIn* a, const TIn* b, TOut* out, int n, size_t batch, size_t sa, size_t sb,
                       size_t so, uint32_t* tmpA, uint32_t* tmpB, hipStream_t st) {
     const bool full = (2 * (size_t)n == ((size_t)CORE_N << Q));
-    static const int minw = env_int("NTT_STRIDED_MINW", Q == 6 ? 2 : 1);
-    if (Q == 6 && minw >= 4) {
-        if (full) launch_multipass_v<Q, LZ, true, 4>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st);
-        else launch_multipass_v<Q, LZ, false, 4>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st);
-    } else if (Q == 6 && minw == 3) {
-        if (full) launch_multipass_v<Q, LZ, true, 3>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st);
-        else launch_multipass_v<Q, LZ, false, 3>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st);
-    } else {
-        if (full) launch_multipass_v<Q, LZ, true, (Q == 6 ? 2 : 1)>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st);
-        else launch_multipass_v<Q, LZ, false, (Q == 6 ? 2 : 1)>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st);
-    }
+    constexpr int MINW = Q == 6 ? 2 : 1;
+    if (full) launch_multipass_v<Q, LZ, true, MINW>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st);
+    else launch_multipass_v<Q, LZ, false, MINW>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st);
 }
 
 template <bool LZ, typename TIn, typename TOut>

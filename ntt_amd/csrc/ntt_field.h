@@ -17,6 +17,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <type_traits>
+
 #if defined(__HIPCC__) || defined(__CUDACC__)
 #define NTT_HD __host__ __device__ __forceinline__
 #else
@@ -41,10 +43,30 @@ NTT_HD uint32_t redc_lazy(uint64_t T, uint32_t p, uint32_t np) {
     return (uint32_t)((T + (uint64_t)m * p) >> 32);
 }
 
-// x - m if x >= m else x, for x < 2m (m <= 2^31): min(x, x - m) on wrapped arithmetic.
+// x - m if x >= m else x, for x < 2m.  m must be wave-uniform (always a modulus, or twice one,
+// from kernel arguments).  On the device: a subtract that writes the borrow plus a select on it.
+// v_min_u32 issues at a fraction of the add rate on gfx950; this form measured 24 % faster than
+// (subtract, min) in a butterfly-shaped instruction mix (tools/ubench_csub.hip), and hipcc turns
+// every C spelling of the select back into the min.
 NTT_HD uint32_t csub(uint32_t x, uint32_t m) {
-    uint32_t t = x - m;
-    return t < x ? t : x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t t, r;
+    asm("v_subrev_co_u32 %0, vcc, %3, %2\n\tv_cndmask_b32 %1, %0, %2, vcc" : "=&v"(t), "=v"(r) : "v"(x), "s"(m) : "vcc");
+    return r;
+#else
+    return x >= m ? x - m : x;
+#endif
+}
+
+// Compile-time loop: f(integral_constant<int, I>) for I in [I0, N).  The register transforms below
+// index their arrays only with these constants, so the arrays stay in registers whatever the
+// optimiser's unrolling limits are.
+template <int I, int N, class F>
+NTT_HD void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
 }
 
 // Field policy.  LZ (p < 2^30): values between butterflies live in [0, 2p) on
@@ -150,17 +172,17 @@ NTT_HD constexpr int bitrev(int x, int bits) {
 template <int Q, bool LZ, bool ZERO_UPPER = false, bool LAZY_OUT = false>
 NTT_HD void dif_reg(uint32_t (&x)[1 << Q], const Field<LZ>& f, const uint32_t (&rootF)[32]) {
     constexpr int N = 1 << Q;
-#pragma unroll
-    for (int s = 0; s < Q; ++s) {
-        const int h = N >> (s + 1);
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            if ((i & h) == 0) {
-                const int e = ((i & (h - 1)) << s) << (6 - Q);  // exponent in units of w64
-                if (ZERO_UPPER && s == 0) {
+    static_for<0, Q>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        constexpr int h = N >> (s + 1);
+        static_for<0, N>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr ((i & h) == 0) {
+                constexpr int e = ((i & (h - 1)) << s) << (6 - Q);  // exponent in units of w64
+                if constexpr (ZERO_UPPER && s == 0) {
                     x[i + h] = (e == 0) ? x[i] : f.mulw(x[i], rootF[e]);
-                } else if (e == 0) {
-                    if (LAZY_OUT && s == Q - 1) {
+                } else if constexpr (e == 0) {
+                    if constexpr (LAZY_OUT && s == Q - 1) {
                         const uint32_t u = x[i], v = x[i + h];
                         x[i] = (i == 0) ? f.add(u, v) : u + v;
                         x[i + h] = f.sub_raw(u, v);
@@ -171,8 +193,8 @@ NTT_HD void dif_reg(uint32_t (&x)[1 << Q], const Field<LZ>& f, const uint32_t (&
                     f.dif(x[i], x[i + h], rootF[e]);
                 }
             }
-        }
-    }
+        });
+    });
 }
 
 // Mirror of dif_reg: x[pos] = X[bitrev_Q(pos)] in, natural order out, times 2^Q.
@@ -180,22 +202,22 @@ NTT_HD void dif_reg(uint32_t (&x)[1 << Q], const Field<LZ>& f, const uint32_t (&
 template <int Q, bool LZ, bool FIRST_REDUCED = false>
 NTT_HD void dit_reg(uint32_t (&x)[1 << Q], const Field<LZ>& f, const uint32_t (&rootI)[32]) {
     constexpr int N = 1 << Q;
-#pragma unroll
-    for (int s = Q - 1; s >= 0; --s) {
-        const int h = N >> (s + 1);
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            if ((i & h) == 0) {
-                const int e = ((i & (h - 1)) << s) << (6 - Q);
-                if (e == 0) {
-                    if (FIRST_REDUCED && s == Q - 1) f.dit1_reduced(x[i], x[i + h]);
+    static_for<0, Q>([&](auto S) {
+        constexpr int s = Q - 1 - decltype(S)::value;
+        constexpr int h = N >> (s + 1);
+        static_for<0, N>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr ((i & h) == 0) {
+                constexpr int e = ((i & (h - 1)) << s) << (6 - Q);
+                if constexpr (e == 0) {
+                    if constexpr (FIRST_REDUCED && s == Q - 1) f.dit1_reduced(x[i], x[i + h]);
                     else f.dit1(x[i], x[i + h]);
                 } else {
                     f.dit(x[i], x[i + h], rootI[e]);
                 }
             }
-        }
-    }
+        });
+    });
 }
 
 }  // namespace nttamd

@@ -39,6 +39,14 @@ namespace nttamd {
 #else
 #define NTT_CORE_SYNC() __syncthreads()
 #endif
+// -DNTT_ABLATE_LDS: the core's LDS exchanges become register pass-throughs
+#ifdef NTT_ABLATE_LDS
+#define NTT_LDS_ST(arr, idx, val) asm volatile("" :: "v"(val))
+#define NTT_LDS_LD(arr, idx, cur) (cur)
+#else
+#define NTT_LDS_ST(arr, idx, val) ((arr)[idx] = (val))
+#define NTT_LDS_LD(arr, idx, cur) ((arr)[idx])
+#endif
 
 constexpr int CORE_N = 4096;   // points per LDS-resident core transform
 constexpr int CORE_T = 256;    // threads per core workgroup (16 points each)
@@ -98,25 +106,25 @@ __device__ __forceinline__ void core_forward2(uint32_t (&a)[16], uint32_t (&b)[1
     for (int pos = 0; pos < 16; ++pos) {
         if (pos) { a[pos] = f.mulw(a[pos], tw[pos]); b[pos] = f.mulw(b[pos], tw[pos]); }
         const int s = core_slot(pos, hi, lo);
-        ldsA[s] = a[pos]; ldsB[s] = b[pos];
+        NTT_LDS_ST(ldsA, s, a[pos]); NTT_LDS_ST(ldsB, s, b[pos]);
     }
     NTT_CORE_SYNC();
     load_tw16(tw, tb.tw2F, lo);
     // round 2
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const int s = core_slot(hi, i, lo); a[i] = ldsA[s]; b[i] = ldsB[s]; }
+    for (int i = 0; i < 16; ++i) { const int s = core_slot(hi, i, lo); a[i] = NTT_LDS_LD(ldsA, s, a[i]); b[i] = NTT_LDS_LD(ldsB, s, b[i]); }
     dif_reg<4, LZ, false, true>(a, f, fc.rootF);
     dif_reg<4, LZ, false, true>(b, f, fc.rootF);
 #pragma unroll
     for (int pos = 0; pos < 16; ++pos) {
         if (pos) { a[pos] = f.mulw(a[pos], tw[pos]); b[pos] = f.mulw(b[pos], tw[pos]); }
         const int s = core_slot(hi, pos, lo);
-        ldsA[s] = a[pos]; ldsB[s] = b[pos];
+        NTT_LDS_ST(ldsA, s, a[pos]); NTT_LDS_ST(ldsB, s, b[pos]);
     }
     NTT_CORE_SYNC();
     // round 3
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const int s = core_slot(hi, lo, i); a[i] = ldsA[s]; b[i] = ldsB[s]; }
+    for (int i = 0; i < 16; ++i) { const int s = core_slot(hi, lo, i); a[i] = NTT_LDS_LD(ldsA, s, a[i]); b[i] = NTT_LDS_LD(ldsB, s, b[i]); }
     dif_reg<4, LZ>(a, f, fc.rootF);
     dif_reg<4, LZ>(b, f, fc.rootF);
 }
@@ -138,25 +146,25 @@ __device__ __forceinline__ void core_inverse(uint32_t (&a)[16], uint32_t* ldsA, 
     // inverse of round 3 (same thread owns the same slots: no barrier before the write)
     dit_reg<4, LZ, true>(a, f, fc.rootI);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ldsA[core_slot(hi, lo, i)] = a[i];
+    for (int i = 0; i < 16; ++i) NTT_LDS_ST(ldsA, core_slot(hi, lo, i), a[i]);
     NTT_FENCE();
     load_tw16(tw, tb.tw2I, lo);  // next round's twiddles travel while the workgroup synchronises
     NTT_CORE_SYNC();
     // inverse of round 2
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        uint32_t v = ldsA[core_slot(hi, i, lo)];
+        uint32_t v = NTT_LDS_LD(ldsA, core_slot(hi, i, lo), a[i]);
         a[i] = i ? f.mulw(v, tw[i]) : (LZ ? csub(v, f.B) : v);
     }
     dit_reg<4, LZ, true>(a, f, fc.rootI);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ldsA[core_slot(hi, i, lo)] = a[i];
+    for (int i = 0; i < 16; ++i) NTT_LDS_ST(ldsA, core_slot(hi, i, lo), a[i]);
     NTT_FENCE();
     load_tw16(tw, tb.tw1I, t);
     NTT_CORE_SYNC();
     // inverse of round 1 (every slot is multiplied: the table carries the scale factor)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = f.mulw(ldsA[core_slot(i, hi, lo)], tw[i]);
+    for (int i = 0; i < 16; ++i) a[i] = f.mulw(NTT_LDS_LD(ldsA, core_slot(i, hi, lo), a[i]), tw[i]);
     dit_reg<4, LZ, true>(a, f, fc.rootI);
 }
 
@@ -165,47 +173,50 @@ __device__ __forceinline__ void core_inverse(uint32_t (&a)[16], uint32_t* ldsA, 
 // (4096 values each) -> same block of tmpC.  tmpC may alias tmpA (a block is fully read before it
 // is written, and other blocks are other addresses).
 // ---------------------------------------------------------------------------
+// One 4096-block: pa/pb/pc point at the block's first value (pc may equal pa).
 template <bool LZ>
-__global__ void __launch_bounds__(CORE_T) k_core_mul(const uint32_t* tmpA, const uint32_t* tmpB, uint32_t* tmpC,
-                                                     FieldConsts fc, CoreTables tb) {
-    __shared__ uint32_t lds[2 * CORE_N];
+__device__ __forceinline__ void core_block(const uint32_t* pa, const uint32_t* pb, uint32_t* pc, uint32_t* lds,
+                                           const FieldConsts& fc, const CoreTables& tb, int t) {
     const Field<LZ> f(fc);
-    const int t = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * CORE_N + t;
     uint32_t a[16], b[16];
 #ifdef NTT_ABLATE_GLOAD
-    for (int i = 0; i < 16; ++i) { a[i] = (uint32_t)base * 2654435761u + i; b[i] = a[i] ^ 12345u; }
+    for (int i = 0; i < 16; ++i) { a[i] = (uint32_t)(size_t)pa * 2654435761u + i + t; b[i] = a[i] ^ 12345u; }
 #else
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { a[i] = tmpA[base + 256 * i]; b[i] = tmpB[base + 256 * i]; }
+    for (int i = 0; i < 16; ++i) { a[i] = pa[t + 256 * i]; b[i] = pb[t + 256 * i]; }
 #endif
     core_forward2<LZ>(a, b, lds, lds + CORE_N, f, fc, tb, t);
     core_pointwise<LZ>(a, b, f);
     core_inverse<LZ>(a, lds, f, fc, tb, t);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tmpC[base + 256 * i] = a[i];
+    for (int i = 0; i < 16; ++i) pc[t + 256 * i] = a[i];
+}
+
+template <bool LZ>
+__global__ void __launch_bounds__(CORE_T) k_core_mul(const uint32_t* tmpA, const uint32_t* tmpB, uint32_t* tmpC,
+                                                     FieldConsts fc, CoreTables tb) {
+#ifdef NTT_CORE_LDS_PAD   // diagnostic: extra LDS lowers the number of resident workgroups
+    __shared__ uint32_t lds[2 * CORE_N + NTT_CORE_LDS_PAD];
+#else
+    __shared__ uint32_t lds[2 * CORE_N];
+#endif
+    const size_t base = (size_t)blockIdx.x * CORE_N;
+    core_block<LZ>(tmpA + base, tmpB + base, tmpC + base, lds, fc, tb, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
-// k_fwd_strided: first pass of a length Lb = C * 2^Q transform on every block of Lb
-// values: thread = column j, registers = the 2^Q rows j + C*r.  PADDED: the source row
-// has only n_valid < = Lb/2 values, the rest are implicit zeros that are never read.
-// Output slot pos*C + j holds (row-transform output bitrev_Q(pos)) * w_Lb^(j*bitrev_Q(pos)).
-// Twiddle table layout: [(pos>>2)][j][pos&3] so a thread's 4 consecutive positions are one
-// 16-byte load and neighbouring threads are contiguous.
-// Grid: x = (C/256) * rows, z = 2 (A and B).
+// Strided passes.  fwd_column: first pass of a length Lb = C * 2^Q transform for one column j:
+// registers = the 2^Q rows j + C*r of src.  PADDED: the source row has only n_valid <= Lb/2
+// values, the rest are implicit zeros that are never read; FULL: n_valid is exactly Lb/2 (no
+// per-element bound check).  Output slot pos*C + j holds (row-transform output bitrev_Q(pos))
+// * w_Lb^(j*bitrev_Q(pos)).  Twiddle table layout: [(pos>>2)][j][pos&3], so a thread's 4
+// consecutive positions are one 16-byte load and neighbouring threads are contiguous.
 // ---------------------------------------------------------------------------
-template <int Q, bool LZ, bool PADDED, bool FULL, int MINW, typename TIn>
-__global__ void __launch_bounds__(256, MINW) k_fwd_strided(const TIn* inA, const TIn* inB, size_t a_stride, size_t b_stride,
-                                                     int n_valid, uint32_t* outA, uint32_t* outB, int C,
-                                                     const uint32_t* T1, FieldConsts fc) {
+template <int Q, bool LZ, bool PADDED, bool FULL, typename TIn>
+__device__ __forceinline__ void fwd_column(const TIn* src, int n_valid, uint32_t* dst, int C, const uint32_t* T1,
+                                           const FieldConsts& fc, int j) {
     constexpr int R = 1 << Q;
     const Field<LZ> f(fc);
-    const int chunks = C >> 8;
-    const int j = (int)(blockIdx.x % chunks) * 256 + threadIdx.x;
-    const size_t row = blockIdx.x / chunks;
-    const TIn* src = (blockIdx.z ? inB + row * b_stride : inA + row * a_stride);
-    uint32_t* dst = (blockIdx.z ? outB : outA) + row * ((size_t)C << Q);
     uint32_t x[R];
     constexpr int G = R / 4;              // 16-byte twiddle groups (4 positions each)
     constexpr int SG = G < 4 ? G : 4;     // groups per pipeline stage
@@ -243,20 +254,13 @@ __global__ void __launch_bounds__(256, MINW) k_fwd_strided(const TIn* inA, const
     }
 }
 
-// ---------------------------------------------------------------------------
-// k_inv_strided: mirror of k_fwd_strided.  FINAL: results are reduced to [0,p) and only
-// indices < n_out are stored (row stride out_stride, type TOut); otherwise the block is
-// written back in place layout (uint32, lazy range).
-// ---------------------------------------------------------------------------
-template <int Q, bool LZ, bool FINAL, bool FULL, int MINW, typename TOut>
-__global__ void __launch_bounds__(256, MINW) k_inv_strided(const uint32_t* in, TOut* out, size_t out_stride, int n_out, int C,
-                                                     const uint32_t* T3, FieldConsts fc) {
+// inv_column: mirror of fwd_column.  FINAL: results are reduced to [0,p) and only indices < n_out
+// are stored; otherwise the block is written back in place layout (uint32, lazy range).
+template <int Q, bool LZ, bool FINAL, bool FULL, typename TOut>
+__device__ __forceinline__ void inv_column(const uint32_t* src, TOut* dst, int n_out, int C, const uint32_t* T3,
+                                           const FieldConsts& fc, int j) {
     constexpr int R = 1 << Q;
     const Field<LZ> f(fc);
-    const int chunks = C >> 8;
-    const int j = (int)(blockIdx.x % chunks) * 256 + threadIdx.x;
-    const size_t row = blockIdx.x / chunks;
-    const uint32_t* src = in + row * ((size_t)C << Q);
     uint32_t x[R];
     constexpr int G = R / 4;
     constexpr int SG = G < 4 ? G : 4;
@@ -287,7 +291,6 @@ __global__ void __launch_bounds__(256, MINW) k_inv_strided(const uint32_t* in, T
         NTT_FENCE();
     }
     dit_reg<Q, LZ, true>(x, f, fc.rootI);
-    TOut* dst = out + row * out_stride;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int idx = j + C * r;
@@ -298,6 +301,28 @@ __global__ void __launch_bounds__(256, MINW) k_inv_strided(const uint32_t* in, T
             dst[idx] = (TOut)x[r];
         }
     }
+}
+
+// Grid: x = (C/256) * rows, z = 2 (A and B).  MINW: waves per SIMD the register allocation must allow.
+template <int Q, bool LZ, bool PADDED, bool FULL, int MINW, typename TIn>
+__global__ void __launch_bounds__(256, MINW) k_fwd_strided(const TIn* inA, const TIn* inB, size_t a_stride, size_t b_stride,
+                                                     int n_valid, uint32_t* outA, uint32_t* outB, int C,
+                                                     const uint32_t* T1, FieldConsts fc) {
+    const int chunks = C >> 8;
+    const int j = (int)(blockIdx.x % chunks) * 256 + threadIdx.x;
+    const size_t row = blockIdx.x / chunks;
+    const TIn* src = (blockIdx.z ? inB + row * b_stride : inA + row * a_stride);
+    uint32_t* dst = (blockIdx.z ? outB : outA) + row * ((size_t)C << Q);
+    fwd_column<Q, LZ, PADDED, FULL, TIn>(src, n_valid, dst, C, T1, fc, j);
+}
+
+template <int Q, bool LZ, bool FINAL, bool FULL, int MINW, typename TOut>
+__global__ void __launch_bounds__(256, MINW) k_inv_strided(const uint32_t* in, TOut* out, size_t out_stride, int n_out, int C,
+                                                     const uint32_t* T3, FieldConsts fc) {
+    const int chunks = C >> 8;
+    const int j = (int)(blockIdx.x % chunks) * 256 + threadIdx.x;
+    const size_t row = blockIdx.x / chunks;
+    inv_column<Q, LZ, FINAL, FULL, TOut>(in + row * ((size_t)C << Q), out + row * out_stride, n_out, C, T3, fc, j);
 }
 
 // ---------------------------------------------------------------------------
