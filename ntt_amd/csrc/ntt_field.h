@@ -33,8 +33,9 @@ struct FieldConsts {
     uint32_t np;      // -p^-1 mod 2^32
     uint32_t r1;      // R mod p      (Montgomery form of 1)
     uint32_t r2;      // R^2 mod p    (Montgomery form of R)
-    uint32_t rootF[32];  // Montgomery form of w64^e,  e = 0..31 (w64 = primitive 64th root, or the
-    uint32_t rootI[32];  // Montgomery form of w64^-e  largest available power when 64 does not divide p-1)
+    uint32_t rootF[32];   // Montgomery form of  w64^e, e = 0..31 (w64 = primitive 64th root; zeros when 64 does not divide p-1)
+    uint32_t rootFn[32];  // Montgomery form of -w64^e  (= p - rootF[e])
+    uint32_t rootI[32];   // Montgomery form of  w64^-e
 };
 
 // (T + m*p) / 2^32 with m = T*np mod 2^32.  For T < 2^32 * p the result is in [0, 2p).
@@ -43,20 +44,8 @@ NTT_HD uint32_t redc_lazy(uint64_t T, uint32_t p, uint32_t np) {
     return (uint32_t)((T + (uint64_t)m * p) >> 32);
 }
 
-// x - m if x >= m else x, for x < 2m.  m must be wave-uniform (always a modulus, or twice one,
-// from kernel arguments).  On the device: a subtract that writes the borrow plus a select on it.
-// v_min_u32 issues at a fraction of the add rate on gfx950; this form measured 24 % faster than
-// (subtract, min) in a butterfly-shaped instruction mix (tools/ubench_csub.hip), and hipcc turns
-// every C spelling of the select back into the min.
-NTT_HD uint32_t csub(uint32_t x, uint32_t m) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t t, r;
-    asm("v_subrev_co_u32 %0, vcc, %3, %2\n\tv_cndmask_b32 %1, %0, %2, vcc" : "=&v"(t), "=v"(r) : "v"(x), "s"(m) : "vcc");
-    return r;
-#else
-    return x >= m ? x - m : x;
-#endif
-}
+// x - m if x >= m else x, for x < 2m.
+NTT_HD uint32_t csub(uint32_t x, uint32_t m) { return x >= m ? x - m : x; }
 
 // Compile-time loop: f(integral_constant<int, I>) for I in [I0, N).  The register transforms below
 // index their arrays only with these constants, so the arrays stay in registers whatever the
@@ -91,10 +80,13 @@ struct Field {
     NTT_HD uint32_t sub_raw(uint32_t u, uint32_t v) const { return u - v + B; }    // (0, 2B), unreduced
     NTT_HD uint32_t sub(uint32_t u, uint32_t v) const { return csub(u - v + B, B); }
 
-    // Gentleman-Sande butterfly, u, v in [0,B) -> [0,B):  u' = u+v, v' = (u-v)*w
-    NTT_HD void dif(uint32_t& u, uint32_t& v, uint32_t wm) const {
+    // Gentleman-Sande butterfly, u, v in [0,B) -> [0,B):  u' = u+v, v' = (u-v)*w.  The difference is
+    // never formed: (u-v)*w = u*w + v*(-w) is accumulated in 64 bits (two multiply-adds) and reduced
+    // once; u*w + v*(p-w) < 2*B*p <= 2^32*p keeps the reduction in range.  wn = Montgomery form of -w.
+    NTT_HD void dif(uint32_t& u, uint32_t& v, uint32_t wm, uint32_t wn) const {
         uint32_t s = add(u, v);
-        v = mulw(sub_raw(u, v), wm);
+        uint32_t r = redc_lazy((uint64_t)u * wm + (uint64_t)v * wn, p, np);
+        v = LZ ? r : csub(r, p);
         u = s;
     }
     NTT_HD void dif1(uint32_t& u, uint32_t& v) const {  // w = 1
@@ -170,7 +162,7 @@ NTT_HD constexpr int bitrev(int x, int bits) {
 // (mulw accepts any 32-bit value), so the last stage skips their reduction and
 // leaves them in [0, 2B).
 template <int Q, bool LZ, bool ZERO_UPPER = false, bool LAZY_OUT = false>
-NTT_HD void dif_reg(uint32_t (&x)[1 << Q], const Field<LZ>& f, const uint32_t (&rootF)[32]) {
+NTT_HD void dif_reg(uint32_t (&x)[1 << Q], const Field<LZ>& f, const uint32_t (&rootF)[32], const uint32_t (&rootFn)[32]) {
     constexpr int N = 1 << Q;
     static_for<0, Q>([&](auto S) {
         constexpr int s = decltype(S)::value;
@@ -190,7 +182,7 @@ NTT_HD void dif_reg(uint32_t (&x)[1 << Q], const Field<LZ>& f, const uint32_t (&
                         f.dif1(x[i], x[i + h]);
                     }
                 } else {
-                    f.dif(x[i], x[i + h], rootF[e]);
+                    f.dif(x[i], x[i + h], rootF[e], rootFn[e]);
                 }
             }
         });

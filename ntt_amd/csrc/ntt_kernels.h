@@ -99,8 +99,8 @@ __device__ __forceinline__ void core_forward2(uint32_t (&a)[16], uint32_t (&b)[1
     uint32_t tw[16];
     const int hi = t >> 4, lo = t & 15;
     // round 1
-    dif_reg<4, LZ, false, true>(a, f, fc.rootF);
-    dif_reg<4, LZ, false, true>(b, f, fc.rootF);
+    dif_reg<4, LZ, false, true>(a, f, fc.rootF, fc.rootFn);
+    dif_reg<4, LZ, false, true>(b, f, fc.rootF, fc.rootFn);
     load_tw16(tw, tb.tw1F, t);
 #pragma unroll
     for (int pos = 0; pos < 16; ++pos) {
@@ -113,8 +113,8 @@ __device__ __forceinline__ void core_forward2(uint32_t (&a)[16], uint32_t (&b)[1
     // round 2
 #pragma unroll
     for (int i = 0; i < 16; ++i) { const int s = core_slot(hi, i, lo); a[i] = NTT_LDS_LD(ldsA, s, a[i]); b[i] = NTT_LDS_LD(ldsB, s, b[i]); }
-    dif_reg<4, LZ, false, true>(a, f, fc.rootF);
-    dif_reg<4, LZ, false, true>(b, f, fc.rootF);
+    dif_reg<4, LZ, false, true>(a, f, fc.rootF, fc.rootFn);
+    dif_reg<4, LZ, false, true>(b, f, fc.rootF, fc.rootFn);
 #pragma unroll
     for (int pos = 0; pos < 16; ++pos) {
         if (pos) { a[pos] = f.mulw(a[pos], tw[pos]); b[pos] = f.mulw(b[pos], tw[pos]); }
@@ -125,8 +125,8 @@ __device__ __forceinline__ void core_forward2(uint32_t (&a)[16], uint32_t (&b)[1
     // round 3
 #pragma unroll
     for (int i = 0; i < 16; ++i) { const int s = core_slot(hi, lo, i); a[i] = NTT_LDS_LD(ldsA, s, a[i]); b[i] = NTT_LDS_LD(ldsB, s, b[i]); }
-    dif_reg<4, LZ>(a, f, fc.rootF);
-    dif_reg<4, LZ>(b, f, fc.rootF);
+    dif_reg<4, LZ>(a, f, fc.rootF, fc.rootFn);
+    dif_reg<4, LZ>(b, f, fc.rootF, fc.rootFn);
 }
 
 // Pointwise product of the two spectra followed by the inverse transform (mirror of
@@ -231,7 +231,7 @@ __device__ __forceinline__ void fwd_column(const TIn* src, int n_valid, uint32_t
 #pragma unroll
     for (int k = 0; k < SG; ++k) wb[0][k] = Tq[(size_t)k * C];
     NTT_FENCE();
-    dif_reg<Q, LZ, PADDED, true>(x, f, fc.rootF);
+    dif_reg<Q, LZ, PADDED, true>(x, f, fc.rootF, fc.rootFn);
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
         if (st + 1 < NS) {
@@ -402,9 +402,9 @@ __global__ void __launch_bounds__(256) k_small(const TIn* A, const TIn* Bp, TOut
         for (int k = t; k < half; k += T) {
             const int j = k & (h - 1);
             const int i = ((k - j) << 1) + j;
-            const uint32_t w = twF[j << s];
-            f.dif(la[i], la[i + h], w);
-            f.dif(lb[i], lb[i + h], w);
+            const uint32_t w = twF[j << s], wn = f.p - w;
+            f.dif(la[i], la[i + h], w, wn);
+            f.dif(lb[i], lb[i + h], w, wn);
         }
         __syncthreads();
     }

@@ -113,12 +113,12 @@ inline bool build_plan_host(uint32_t p, int logL, PlanHost& h, std::string* err)
     const uint64_t L = 1ull << logL;
     const uint64_t R1 = (1ull << 32) % p;
     h.fc.p = p; h.fc.np = h_neg_inv32(p); h.fc.r1 = (uint32_t)R1; h.fc.r2 = (uint32_t)h_mulmod(R1, R1, p);
-    for (int e = 0; e < 32; ++e) { h.fc.rootF[e] = 0; h.fc.rootI[e] = 0; }
+    for (int e = 0; e < 32; ++e) { h.fc.rootF[e] = 0; h.fc.rootFn[e] = 0; h.fc.rootI[e] = 0; }
     if ((p - 1) % 64 == 0) {
         const uint64_t w64 = h_powmod(3, (p - 1) / 64, p), w64i = h_powmod(w64, p - 2, p);
         uint64_t a = 1, b = 1;
         for (int e = 0; e < 32; ++e) {
-            h.fc.rootF[e] = h_mont(a, p); h.fc.rootI[e] = h_mont(b, p);
+            h.fc.rootF[e] = h_mont(a, p); h.fc.rootFn[e] = p - h.fc.rootF[e]; h.fc.rootI[e] = h_mont(b, p);
             a = h_mulmod(a, w64, p); b = h_mulmod(b, w64i, p);
         }
     }
