@@ -97,6 +97,38 @@ int ntt_crt_residue_product_device(const uint64_t *d_a, const uint64_t *d_b, uin
                                    void *workspace, size_t workspace_bytes, void *stream);
 uint32_t ntt_crt_prime(int prime_index);
 
+/* ---- 64-bit prime field (odd p < 2^60 with 2^log_root | p-1 and 3 generating that subgroup) ----
+ * Building blocks of one very long product (transform length beyond the 2-adicity of any 32-bit NTT
+ * prime), on one GPU or sharded over ranks with an all-to-all between the two axes of the four-step
+ * matrix.  They take the place of the reference's distributed single transform, which replicates the
+ * array and all-reduces it after every stage (main_mpi_t.cc:139-291).  All pointers are device
+ * pointers, all calls asynchronous on `stream`.  log_root = log2 of the full transform length of the
+ * product; every call of one product passes the same value (it selects the root-of-unity tables).
+ *
+ * ntt64_transform_device: in-place transform of length 2^log_len along the middle axis of an
+ *   [outer][2^log_len][inner] array.  Forward: natural order in, bit-reversed order out, values
+ *   in [0,2p).  Inverse: bit-reversed in, natural out, unscaled, values in [0,4p).
+ * ntt64_twiddle_device: data[r][c] *= w^(+-k(r) * (col0+c)), w of order 2^log_root, for a rows x cols
+ *   tile whose first row/column are row0/col0 of the four-step matrix; k(r) = row0+r, bit-reversed
+ *   over row_bits bits when rows_bitrev != 0 (the order a forward row-axis transform leaves).
+ * ntt64_pointwise_device: a[i] = a[i]*b[i]*2^-64 mod p (the factor is undone by ntt64_finalize_device).
+ * ntt64_load_device: dst[row][i] = i < n ? src[row*src_stride + i] mod p : 0, i < len (may be in place).
+ * ntt64_finalize_device: out[row*out_stride + i] = data[row*len + i] * 2^-log_total * 2^64 mod p, canonical.
+ * ntt64_poly_multiply_device: the whole product on one GPU: d_out[0..2n-2] = a*b mod p.  Same results
+ *   as the CRT route of ntt_poly_multiply_batched_device_u64 wherever both apply. */
+int ntt64_transform_device(uint64_t *d_data, uint64_t p, int log_root, int log_len, size_t inner, size_t outer,
+                           int inverse, void *stream);
+int ntt64_twiddle_device(uint64_t *d_data, uint64_t p, int log_root, size_t rows, size_t cols, uint64_t row0,
+                         uint64_t col0, int row_bits, int rows_bitrev, int inverse, void *stream);
+int ntt64_pointwise_device(uint64_t *d_a, const uint64_t *d_b, size_t count, uint64_t p, int log_root, void *stream);
+int ntt64_load_device(const uint64_t *d_src, size_t src_stride, size_t n, uint64_t *d_dst, size_t len, size_t rows,
+                      uint64_t p, int log_root, void *stream);
+int ntt64_finalize_device(const uint64_t *d_data, size_t len, uint64_t *d_out, size_t out_stride, size_t n_out,
+                          size_t rows, uint64_t p, int log_root, int log_total, void *stream);
+size_t ntt64_workspace_bytes(size_t n);
+int ntt64_poly_multiply_device(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n, uint64_t p,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
 /* Per-kernel timing for benchmarks (no counterpart in the reference, whose only clock is the
  * chrono pair around the multiply, main_naive.cc:251-261).  While enabled, every kernel launch is
  * bracketed by HIP events on the stream it is launched on.  ntt_profile_read waits for the

@@ -24,6 +24,8 @@ EXPORTS = [
     "ntt_poly_multiply_batched", "ntt_poly_multiply_batched_u64",
     "ntt_workspace_bytes", "ntt_poly_multiply_batched_device", "ntt_poly_multiply_batched_device_u64",
     "ntt_crt_merge_device", "ntt_crt_residue_product_device", "ntt_crt_prime", "ntt_describe_plan",
+    "ntt64_transform_device", "ntt64_twiddle_device", "ntt64_pointwise_device", "ntt64_load_device",
+    "ntt64_finalize_device", "ntt64_workspace_bytes", "ntt64_poly_multiply_device",
 ]
 
 
@@ -68,6 +70,14 @@ class NttLibrary:
         L.ntt_crt_residue_product_device.restype = ctypes.c_int
         L.ntt_crt_prime.argtypes = [ctypes.c_int]; L.ntt_crt_prime.restype = ctypes.c_uint32
         L.ntt_describe_plan.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t]; L.ntt_describe_plan.restype = ctypes.c_int
+        vp, u64, sz, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int
+        L.ntt64_transform_device.argtypes = [vp, u64, ci, ci, sz, sz, ci, vp]; L.ntt64_transform_device.restype = ci
+        L.ntt64_twiddle_device.argtypes = [vp, u64, ci, sz, sz, u64, u64, ci, ci, ci, vp]; L.ntt64_twiddle_device.restype = ci
+        L.ntt64_pointwise_device.argtypes = [vp, vp, sz, u64, ci, vp]; L.ntt64_pointwise_device.restype = ci
+        L.ntt64_load_device.argtypes = [vp, sz, sz, vp, sz, sz, u64, ci, vp]; L.ntt64_load_device.restype = ci
+        L.ntt64_finalize_device.argtypes = [vp, sz, vp, sz, sz, sz, u64, ci, ci, vp]; L.ntt64_finalize_device.restype = ci
+        L.ntt64_workspace_bytes.argtypes = [sz]; L.ntt64_workspace_bytes.restype = sz
+        L.ntt64_poly_multiply_device.argtypes = [vp, vp, vp, sz, u64, vp, sz, vp]; L.ntt64_poly_multiply_device.restype = ci
 
     # -- helpers ---------------------------------------------------------
     def check(self, status):

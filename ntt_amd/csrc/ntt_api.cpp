@@ -27,6 +27,7 @@
 
 #include "../../include/ntt_amd.h"
 #include "ntt_kernels.h"
+#include "ntt_kernels64.h"
 #include "ntt_plan.h"
 
 using namespace nttamd;
@@ -70,10 +71,19 @@ struct Plan {
     CoreTables core{};
 };
 
+// 64-bit field: constants and the two-level twiddle tables for the root of order 2^log_root
+struct Plan64 {
+    Field64Consts fc{};
+    Twiddle64 tw{};
+    int log_root = 0;
+    DevBuf tables;
+};
+
 struct Device {
     int id = 0;
     hipStream_t stream = nullptr;
     std::map<std::pair<uint32_t, int>, std::unique_ptr<Plan>> plans;
+    std::map<std::pair<uint64_t, int>, std::unique_ptr<struct Plan64>> plans64;
     DevBuf work;     // library-owned workspace
     DevBuf io_a, io_b, io_out;  // staging for the host-pointer entry points
 };
@@ -309,6 +319,130 @@ int crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, uint64
     return NTT_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 64-bit field path
+// ---------------------------------------------------------------------------------------------
+bool modulus64_ok(uint64_t p, int log_root, std::string* why) {
+    if (p >= (1ull << 60) || p < 3 || (p & 1) == 0) { *why = "64-bit path needs an odd modulus below 2^60"; return false; }
+    if (log_root < 1 || log_root > 40) { *why = "root order out of range"; return false; }
+    const uint64_t L = 1ull << log_root;
+    if ((p - 1) % L != 0) { *why = "transform length does not divide p-1"; return false; }
+    const uint64_t w = h_powmod(3, (p - 1) / L, p);
+    if (h_powmod(w, L / 2, p) != p - 1) { *why = "3 is not a generator of the required 2-power subgroup mod p (p not prime?)"; return false; }
+    return true;
+}
+
+uint64_t h_mont64(uint64_t x, uint64_t p) { return (uint64_t)(((u128)(x % p) << 64) % p); }
+
+int get_plan64(Device* dev, uint64_t p, int log_root, Plan64** out) {
+    auto key = std::make_pair(p, log_root);
+    auto it = dev->plans64.find(key);
+    if (it != dev->plans64.end()) { *out = it->second.get(); return NTT_OK; }
+    std::string why;
+    if (!modulus64_ok(p, log_root, &why)) return fail(NTT_ERR_MODULUS, why);
+    std::unique_ptr<Plan64> pl(new Plan64());
+    pl->log_root = log_root;
+    Field64Consts& fc = pl->fc;
+    fc.p = p;
+    uint64_t inv = p;  // Newton iteration for p^-1 mod 2^64
+    for (int i = 0; i < 6; ++i) inv *= 2 - p * inv;
+    fc.np = 0 - inv;
+    fc.r1 = h_mont64(1, p);
+    fc.r2 = h_mont64(fc.r1, p);
+    const uint64_t wL = h_powmod(3, (p - 1) >> log_root, p);
+    for (int e = 0; e < 8; ++e) { fc.root16F[e] = 0; fc.root16I[e] = 0; }
+    if (log_root >= 4) {
+        const uint64_t w16 = h_powmod(wL, 1ull << (log_root - 4), p), w16i = h_powmod(w16, p - 2, p);
+        uint64_t a = 1, b = 1;
+        for (int e = 0; e < 8; ++e) {
+            fc.root16F[e] = h_mont64(a, p); fc.root16I[e] = h_mont64(b, p);
+            a = h_mulmod(a, w16, p); b = h_mulmod(b, w16i, p);
+        }
+    } else {  // shorter transforms only use the low exponents that exist: w16^(e * 16/2^Q) with 2^Q <= root order
+        for (int e = 0; e < 8; ++e) {
+            if ((e << log_root) % 16 == 0) {
+                fc.root16F[e] = h_mont64(h_powmod(wL, (uint64_t)(e << log_root) / 16, p), p);
+                fc.root16I[e] = h_mont64(h_powmod(wL, (1ull << log_root) - (uint64_t)(e << log_root) / 16, p), p);
+            }
+        }
+    }
+    const int t0 = log_root > LOCAL64_LOG ? log_root - LOCAL64_LOG : 0;
+    const size_t n0 = (size_t)1 << t0, n1 = (size_t)1 << (log_root - t0);
+    std::vector<uint64_t> img(n0 + n1);
+    uint64_t a = 1;
+    for (size_t i = 0; i < n0; ++i) { img[i] = h_mont64(a, p); a = h_mulmod(a, wL, p); }
+    const uint64_t wstep = h_powmod(wL, n0, p);
+    a = 1;
+    for (size_t i = 0; i < n1; ++i) { img[n0 + i] = h_mont64(a, p); a = h_mulmod(a, wstep, p); }
+    int rc = pl->tables.ensure(img.size() * sizeof(uint64_t));
+    if (rc != NTT_OK) return rc;
+    HIP_TRY(hipMemcpy(pl->tables.ptr, img.data(), img.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    pl->tw.w0 = (const uint64_t*)pl->tables.ptr;
+    pl->tw.w1 = pl->tw.w0 + n0;
+    pl->tw.t0 = t0;
+    pl->tw.logtab = log_root;
+    *out = pl.get();
+    dev->plans64[key] = std::move(pl);
+    return NTT_OK;
+}
+
+template <bool INV>
+int launch_strided64(const Plan64& pl, uint64_t* d, int q, const Pass64& g, hipStream_t st) {
+    const unsigned grid = (unsigned)((g.n_threads + 255) / 256);
+    switch (q) {
+        case 1: NTT_LAUNCH_P("k64_strided", (k64_strided<1, INV>), dim3(grid), dim3(256), st, d, g, pl.fc, pl.tw); break;
+        case 2: NTT_LAUNCH_P("k64_strided", (k64_strided<2, INV>), dim3(grid), dim3(256), st, d, g, pl.fc, pl.tw); break;
+        case 3: NTT_LAUNCH_P("k64_strided", (k64_strided<3, INV>), dim3(grid), dim3(256), st, d, g, pl.fc, pl.tw); break;
+        default: NTT_LAUNCH_P("k64_strided", (k64_strided<4, INV>), dim3(grid), dim3(256), st, d, g, pl.fc, pl.tw); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+
+// in-place transform along the middle axis of [outer][2^log_len][inner]
+int transform64(const Plan64& pl, uint64_t* d, int log_len, size_t inner, size_t outer, bool inverse, hipStream_t st) {
+    if (log_len > pl.log_root) return fail(NTT_ERR_ARG, "transform longer than the plan's root order");
+    if (log_len == 0 || outer == 0 || inner == 0) return NTT_OK;
+    const int stop = inner == 1 ? (log_len < LOCAL64_LOG ? log_len : LOCAL64_LOG) : 0;
+    struct Step { int cur, q; };
+    std::vector<Step> steps;
+    for (int cur = log_len; cur > stop;) {
+        const int q = cur - stop < 4 ? cur - stop : 4;
+        steps.push_back({cur, q});
+        cur -= q;
+    }
+    auto strided = [&](const Step& s) -> int {
+        Pass64 g;
+        g.cq = (uint64_t)1 << (s.cur - s.q);
+        g.inner = inner;
+        g.n_threads = ((uint64_t)outer << (log_len - s.cur)) * g.cq * inner;
+        g.tw_stride = (uint64_t)1 << (pl.log_root - s.cur);
+        g.tw_mask = ((uint64_t)1 << pl.log_root) - 1;
+        if (g.n_threads / 256 >= (1ull << 31)) return fail(NTT_ERR_ARG, "transform too large for one launch");
+        return inverse ? launch_strided64<true>(pl, d, s.q, g, st) : launch_strided64<false>(pl, d, s.q, g, st);
+    };
+    auto local = [&]() -> int {
+        if (stop == 0) return NTT_OK;
+        const uint64_t n_blocks = (uint64_t)outer << (log_len - stop);
+        const unsigned grid = (unsigned)(n_blocks < (1u << 20) ? n_blocks : (1u << 20));
+        if (inverse) NTT_LAUNCH_P("k64_local", (k64_local<true>), dim3(grid), dim3(256), st, d, stop, n_blocks, pl.fc, pl.tw);
+        else NTT_LAUNCH_P("k64_local", (k64_local<false>), dim3(grid), dim3(256), st, d, stop, n_blocks, pl.fc, pl.tw);
+        HIP_TRY(hipGetLastError());
+        return NTT_OK;
+    };
+    int rc;
+    if (!inverse) {
+        for (const Step& s : steps) if ((rc = strided(s)) != NTT_OK) return rc;
+        return local();
+    }
+    if ((rc = local()) != NTT_OK) return rc;
+    for (size_t i = steps.size(); i-- > 0;) if ((rc = strided(steps[i])) != NTT_OK) return rc;
+    return NTT_OK;
+}
+
+unsigned grid_for(uint64_t count) { return (unsigned)((count + 255) / 256); }
+
 int check_args(const void* a, const void* b, const void* ab, int n, size_t batch) {
     if (!a || !b || !ab) return fail(NTT_ERR_ARG, "null pointer");
     if (n < 1) return fail(NTT_ERR_ARG, "n must be at least 1");
@@ -386,6 +520,8 @@ void ntt_shutdown(void) {
         (void)e;
         for (auto& kv : dev->plans) kv.second->tables.release();
         dev->plans.clear();
+        for (auto& kv : dev->plans64) kv.second->tables.release();
+        dev->plans64.clear();
         dev->work.release(); dev->io_a.release(); dev->io_b.release(); dev->io_out.release();
         if (dev->stream) { e = hipStreamDestroy(dev->stream); (void)e; }
     }
@@ -526,6 +662,128 @@ void poly_multiply(const int* a, const int* b, int* ab, int n, int p) {
 
 void poly_multiply_u64(const uint64_t* a, const uint64_t* b, uint64_t* ab, int n, uint64_t p) {
     if (ntt_poly_multiply_u64(a, b, ab, n, p) != NTT_OK) die("poly_multiply_u64");
+}
+
+// ---- 64-bit field entry points -------------------------------------------------------------
+int ntt64_transform_device(uint64_t* d_data, uint64_t p, int log_root, int log_len, size_t inner, size_t outer, int inverse,
+                           void* stream) {
+    if (!d_data) return fail(NTT_ERR_ARG, "null pointer");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    Plan64* pl = nullptr;
+    if ((rc = get_plan64(dev, p, log_root, &pl)) != NTT_OK) return rc;
+    return transform64(*pl, d_data, log_len, inner, outer, inverse != 0, (hipStream_t)stream);
+}
+
+int ntt64_twiddle_device(uint64_t* d_data, uint64_t p, int log_root, size_t rows, size_t cols, uint64_t row0, uint64_t col0,
+                         int row_bits, int rows_bitrev, int inverse, void* stream) {
+    if (!d_data) return fail(NTT_ERR_ARG, "null pointer");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    Plan64* pl = nullptr;
+    if ((rc = get_plan64(dev, p, log_root, &pl)) != NTT_OK) return rc;
+    if (rows == 0 || cols == 0) return NTT_OK;
+    NTT_LAUNCH_P("k64_twiddle", k64_twiddle, dim3(grid_for((uint64_t)rows * cols)), dim3(256), (hipStream_t)stream, d_data,
+                 (uint64_t)rows, (uint64_t)cols, row0, col0, row_bits, rows_bitrev, inverse, (uint64_t)1,
+                 ((uint64_t)1 << log_root) - 1, pl->fc, pl->tw);
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+
+int ntt64_pointwise_device(uint64_t* d_a, const uint64_t* d_b, size_t count, uint64_t p, int log_root, void* stream) {
+    if (!d_a || !d_b) return fail(NTT_ERR_ARG, "null pointer");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    Plan64* pl = nullptr;
+    if ((rc = get_plan64(dev, p, log_root, &pl)) != NTT_OK) return rc;
+    if (count == 0) return NTT_OK;
+    NTT_LAUNCH_P("k64_pointwise", k64_pointwise, dim3(grid_for(count)), dim3(256), (hipStream_t)stream, d_a, d_b, (uint64_t)count,
+                 pl->fc);
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+
+int ntt64_load_device(const uint64_t* d_src, size_t src_stride, size_t n, uint64_t* d_dst, size_t len, size_t rows, uint64_t p,
+                      int log_root, void* stream) {
+    if (!d_src || !d_dst) return fail(NTT_ERR_ARG, "null pointer");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    Plan64* pl = nullptr;
+    if ((rc = get_plan64(dev, p, log_root, &pl)) != NTT_OK) return rc;
+    if (rows == 0 || len == 0) return NTT_OK;
+    NTT_LAUNCH_P("k64_load", k64_load, dim3(grid_for((uint64_t)rows * len)), dim3(256), (hipStream_t)stream, d_src, src_stride,
+                 (uint64_t)n, d_dst, (uint64_t)len, (uint64_t)rows, pl->fc);
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+
+int ntt64_finalize_device(const uint64_t* d_data, size_t len, uint64_t* d_out, size_t out_stride, size_t n_out, size_t rows,
+                          uint64_t p, int log_root, int log_total, void* stream) {
+    if (!d_data || !d_out) return fail(NTT_ERR_ARG, "null pointer");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    Plan64* pl = nullptr;
+    if ((rc = get_plan64(dev, p, log_root, &pl)) != NTT_OK) return rc;
+    if (rows == 0 || n_out == 0) return NTT_OK;
+    // scale = L^-1 * R (the R undoes the R^-1 left by the pointwise product), in Montgomery form
+    const uint64_t Linv = h_powmod((1ull << log_total) % p, p - 2, p);
+    const uint64_t scale_m = h_mont64(h_mulmod(Linv, pl->fc.r1, p), p);
+    NTT_LAUNCH_P("k64_finalize", k64_finalize, dim3(grid_for((uint64_t)rows * n_out)), dim3(256), (hipStream_t)stream, d_data,
+                 (uint64_t)len, d_out, out_stride, (uint64_t)n_out, (uint64_t)rows, scale_m, pl->fc);
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+
+size_t ntt64_workspace_bytes(size_t n) {
+    if (n < 1) return 0;
+    const int logL = ceil_log2(2 * (uint64_t)n - 1) < 1 ? 1 : ceil_log2(2 * (uint64_t)n - 1);
+    return 2 * ((size_t)1 << logL) * sizeof(uint64_t);
+}
+
+int ntt64_poly_multiply_device(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n, uint64_t p, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if (!d_a || !d_b || !d_out) return fail(NTT_ERR_ARG, "null pointer");
+    if (n < 1 || n > ((size_t)1 << 34)) return fail(NTT_ERR_ARG, "n out of range");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    int logL = ceil_log2(2 * (uint64_t)n - 1);
+    if (logL < 1) logL = 1;
+    Plan64* pl = nullptr;
+    if ((rc = get_plan64(dev, p, logL, &pl)) != NTT_OK) return rc;
+    const size_t L = (size_t)1 << logL, need = 2 * L * sizeof(uint64_t);
+    if (workspace) {
+        if (workspace_bytes < need) return fail(NTT_ERR_WORKSPACE, "workspace too small");
+    } else {
+        if ((rc = dev->work.ensure(need)) != NTT_OK) return rc;
+        workspace = dev->work.ptr;
+    }
+    uint64_t* wa = (uint64_t*)workspace;
+    uint64_t* wb = wa + L;
+    hipStream_t st = (hipStream_t)stream;
+    NTT_LAUNCH_P("k64_load", k64_load, dim3(grid_for(L)), dim3(256), st, d_a, (size_t)0, (uint64_t)n, wa, (uint64_t)L, (uint64_t)1, pl->fc);
+    NTT_LAUNCH_P("k64_load", k64_load, dim3(grid_for(L)), dim3(256), st, d_b, (size_t)0, (uint64_t)n, wb, (uint64_t)L, (uint64_t)1, pl->fc);
+    if ((rc = transform64(*pl, wa, logL, 1, 1, false, st)) != NTT_OK) return rc;
+    if ((rc = transform64(*pl, wb, logL, 1, 1, false, st)) != NTT_OK) return rc;
+    NTT_LAUNCH_P("k64_pointwise", k64_pointwise, dim3(grid_for(L)), dim3(256), st, wa, (const uint64_t*)wb, (uint64_t)L, pl->fc);
+    if ((rc = transform64(*pl, wa, logL, 1, 1, true, st)) != NTT_OK) return rc;
+    const uint64_t Linv = h_powmod((uint64_t)L % p, p - 2, p);
+    const uint64_t scale_m = h_mont64(h_mulmod(Linv, pl->fc.r1, p), p);
+    NTT_LAUNCH_P("k64_finalize", k64_finalize, dim3(grid_for(2 * n - 1)), dim3(256), st, (const uint64_t*)wa, (uint64_t)L, d_out,
+                 (size_t)0, (uint64_t)(2 * n - 1), (uint64_t)1, scale_m, pl->fc);
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
 }
 
 int ntt_profile_enable(int on) {

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "ntt_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return set(re.findall(r"\b((?:ntt_|poly_multiply)\w*)\s*\(", text))
+    return set(re.findall(r"\b((?:ntt_|ntt64_|poly_multiply)\w*)\s*\(", text))
 
 
 def test_header_and_binding_agree():

@@ -87,3 +87,49 @@ def test_error_reporting(twin):
     assert twin.describe_plan(4096, 998244353) == "k_fused8192"
     assert twin.describe_plan(4, BIGP).endswith("k_crt_merge")
     assert twin.lib.ntt_workspace_bytes(131072, 998244353, 4) == 2 * 4 * (1 << 18) * 4
+
+
+# ---- 64-bit field path -------------------------------------------------------------------------
+def _twin_mul64(twin, a, b, p):
+    import torch
+    n = len(a)
+    ta = torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64).copy())
+    tb = torch.from_numpy(np.ascontiguousarray(b, dtype=np.uint64).view(np.int64).copy())
+    out = torch.zeros(2 * n - 1, dtype=torch.int64)
+    twin.check(twin.lib.ntt64_poly_multiply_device(ta.data_ptr(), tb.data_ptr(), out.data_ptr(), n, p, None, 0, None))
+    return out.numpy().view(np.uint64)
+
+
+def test_64bit_field_product(twin, oracle):
+    rng = np.random.default_rng(64)
+    for p in (BIGP, 998244353):
+        for n in (1, 2, 3, 8, 100, 2048, 4096, 5000, 8192, 32768):
+            a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
+            m = 1 << (n - 1).bit_length() if n > 1 else 1
+            az = np.zeros(m, dtype=np.uint64); bz = np.zeros(m, dtype=np.uint64); az[:n] = a; bz[:n] = b
+            want = oracle.poly_multiply_u64(az, bz, p)[:2 * n - 1]
+            assert np.array_equal(_twin_mul64(twin, a, b, p), want), (p, n)
+    a = rng.integers(0, 2**64, 300, dtype=np.uint64); b = rng.integers(0, 2**64, 300, dtype=np.uint64)
+    assert np.array_equal(_twin_mul64(twin, a, b, BIGP), oracle.schoolbook_u64(a % BIGP, b % BIGP, BIGP))
+
+
+def test_64bit_field_rejects_unfriendly_moduli(twin):
+    from ntt_amd._binding import NttError
+    a = np.ones(8, dtype=np.uint64)
+    with pytest.raises(NttError):
+        _twin_mul64(twin, a, a, 1000000007)      # 16 does not divide p-1
+    with pytest.raises(NttError):
+        _twin_mul64(twin, a, a, 2**61 - 1)       # above the 2^60 limit
+
+
+def test_explicit_fourstep_matrix_form(twin, oracle):
+    import torch
+    from ntt_amd.fourstep import poly_multiply_fourstep, plan_shape
+    rng = np.random.default_rng(4)
+    for n in (1, 2, 7, 64, 1000, 4096, 30000):
+        a = rng.integers(0, BIGP, n, dtype=np.uint64); b = rng.integers(0, BIGP, n, dtype=np.uint64)
+        m = 1 << (n - 1).bit_length() if n > 1 else 1
+        az = np.zeros(m, dtype=np.uint64); bz = np.zeros(m, dtype=np.uint64); az[:n] = a; bz[:n] = b
+        want = oracle.crt_ntt_multiply(az, bz, BIGP)[:2 * n - 1]
+        assert np.array_equal(poly_multiply_fourstep(twin, a, b, BIGP, torch.device("cpu")), want), n
+    assert plan_shape(1 << 28, 8) == (29, 14, 15)

@@ -64,9 +64,18 @@ got3 = crt_multiply_distributed(lib, A3, B3, P, dist, torch.device("cpu"))
 ok3 = all(np.array_equal(got3[r], orc.crt_ntt_multiply(A3[r], B3[r], P)) for r in range(3))
 got4 = crt_multiply_distributed(lib, A[:1000], B[:1000], P, dist, torch.device("cpu"))
 ok3 = ok3 and np.array_equal(got4, orc.schoolbook_u64(A[:1000], B[:1000], P))
+# 4. one long product by the four-step transform in the 64-bit field, matrix sharded over the ranks,
+#    all-to-all between the two transform axes (3 per product)
+from ntt_amd.fourstep import poly_multiply_fourstep
+ok4 = True
+for n4 in (4096, 1000, 16384):
+    A4 = rng.integers(0, P, n4, dtype=np.uint64); B4 = rng.integers(0, P, n4, dtype=np.uint64)
+    got = poly_multiply_fourstep(lib, A4, B4, P, torch.device("cpu"), dist)
+    want = orc.crt_ntt_multiply(A4, B4, P) if n4 & (n4 - 1) == 0 else orc.schoolbook_u64(A4, B4, P)
+    ok4 = ok4 and np.array_equal(got, want)
 slow = max_over_ranks(float(rank + 1), dist)
 if rank == 0:
-    print(json.dumps({"batched": bool(ok1), "crt": bool(ok2), "crt_packaged": bool(ok3), "max": slow, "world": world}))
+    print(json.dumps({"batched": bool(ok1), "crt": bool(ok2), "crt_packaged": bool(ok3), "fourstep": bool(ok4), "max": slow, "world": world}))
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -100,4 +109,4 @@ def test_two_gloo_ranks_shard_batch_and_crt_primes(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out == {"batched": True, "crt": True, "crt_packaged": True, "max": 2.0, "world": 2}
+    assert out == {"batched": True, "crt": True, "crt_packaged": True, "fourstep": True, "max": 2.0, "world": 2}
