@@ -443,10 +443,62 @@ int transform64(const Plan64& pl, uint64_t* d, int log_len, size_t inner, size_t
 
 unsigned grid_for(uint64_t count) { return (unsigned)((count + 255) / 256); }
 
+// whole products in the 64-bit field, one row after the other through one workspace
+int field64_product_device(Device* dev, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint64_t p, size_t batch,
+                           size_t sa, size_t sb, size_t so, void* ws, size_t ws_bytes, hipStream_t st) {
+    int logL = ceil_log2(2 * (uint64_t)n - 1);
+    if (logL < 1) logL = 1;
+    Plan64* pl = nullptr;
+    int rc = get_plan64(dev, p, logL, &pl);
+    if (rc != NTT_OK) return rc;
+    const size_t L = (size_t)1 << logL, need = 2 * L * sizeof(uint64_t);
+    if (ws) {
+        if (ws_bytes < need) return fail(NTT_ERR_WORKSPACE, "workspace too small");
+    } else {
+        if ((rc = dev->work.ensure(need)) != NTT_OK) return rc;
+        ws = dev->work.ptr;
+    }
+    uint64_t* wa = (uint64_t*)ws;
+    uint64_t* wb = wa + L;
+    const uint64_t Linv = h_powmod((uint64_t)L % p, p - 2, p);
+    const uint64_t scale_m = h_mont64(h_mulmod(Linv, pl->fc.r1, p), p);
+    for (size_t row = 0; row < batch; ++row) {
+        NTT_LAUNCH_P("k64_load", k64_load, dim3(grid_for(L)), dim3(256), st, a + row * sa, (size_t)0, (uint64_t)n, wa, (uint64_t)L, (uint64_t)1, pl->fc);
+        NTT_LAUNCH_P("k64_load", k64_load, dim3(grid_for(L)), dim3(256), st, b + row * sb, (size_t)0, (uint64_t)n, wb, (uint64_t)L, (uint64_t)1, pl->fc);
+        if ((rc = transform64(*pl, wa, logL, 1, 1, false, st)) != NTT_OK) return rc;
+        if ((rc = transform64(*pl, wb, logL, 1, 1, false, st)) != NTT_OK) return rc;
+        NTT_LAUNCH_P("k64_pointwise", k64_pointwise, dim3(grid_for(L)), dim3(256), st, wa, (const uint64_t*)wb, (uint64_t)L, pl->fc);
+        if ((rc = transform64(*pl, wa, logL, 1, 1, true, st)) != NTT_OK) return rc;
+        NTT_LAUNCH_P("k64_finalize", k64_finalize, dim3(grid_for(2 * n - 1)), dim3(256), st, (const uint64_t*)wa, (uint64_t)L,
+                     out + row * so, (size_t)0, (uint64_t)(2 * n - 1), (uint64_t)1, scale_m, pl->fc);
+        HIP_TRY(hipGetLastError());
+    }
+    return NTT_OK;
+}
+
+// Which arithmetic serves (n, p):
+//   32-bit direct  p < 2^31 NTT-friendly and L <= 2^18 (every case the reference's NTT_multiply covers)
+//   four-prime CRT any p with n*(p-1)^2 below the product of the primes, L <= 2^18 (the reference's route for p > 2^32)
+//   64-bit field   p < 2^60 with L | p-1: lengths and moduli beyond both of the above
+enum Route { ROUTE_DIRECT32, ROUTE_CRT, ROUTE_FIELD64, ROUTE_NONE };
+constexpr int MAX_LOG_L32 = 18;
+
+Route choose_route(uint64_t p, size_t n, std::string* why) {
+    int logL = ceil_log2(2 * (uint64_t)n - 1);
+    if (logL < 1) logL = 1;
+    if (logL <= MAX_LOG_L32 && direct_path_ok(p, logL)) return ROUTE_DIRECT32;
+    if (logL <= MAX_LOG_L32 && n < (1u << 30) && crt_bound_ok((int)n, p)) return ROUTE_CRT;
+    std::string w64;
+    if (modulus64_ok(p, logL, &w64)) return ROUTE_FIELD64;
+    if (why) *why = "no exact route for this modulus and length: the four-prime CRT needs n*(p-1)^2 < 2^118.9 and length <= 2^18; "
+                    "the 64-bit field needs " + w64;
+    return ROUTE_NONE;
+}
+
 int check_args(const void* a, const void* b, const void* ab, int n, size_t batch) {
     if (!a || !b || !ab) return fail(NTT_ERR_ARG, "null pointer");
     if (n < 1) return fail(NTT_ERR_ARG, "n must be at least 1");
-    if (batch > 0 && transform_log2(n) > MAX_LOG_L) return fail(NTT_ERR_ARG, "n too large");
+    if (n > (1 << 30)) return fail(NTT_ERR_ARG, "n too large");
     if (batch >= (1ull << 31) / 64) return fail(NTT_ERR_ARG, "batch too large for one launch");
     return NTT_OK;
 }
@@ -537,9 +589,14 @@ uint32_t ntt_crt_prime(int i) { return (i >= 0 && i < 4) ? kCrtPrimes[i] : 0; }
 
 size_t ntt_workspace_bytes(int n, uint64_t p, size_t batch) {
     if (n < 1) return 0;
-    const int logL = transform_log2(n);
-    if (logL > MAX_LOG_L) return 0;
-    return direct_path_ok(p, logL) ? pipeline_workspace_bytes(logL, batch) : crt_workspace_bytes(logL, batch);
+    int logL = ceil_log2(2 * (uint64_t)n - 1);
+    if (logL < 1) logL = 1;
+    switch (choose_route(p, (size_t)n, nullptr)) {
+        case ROUTE_DIRECT32: return pipeline_workspace_bytes(logL, batch);
+        case ROUTE_CRT: return crt_workspace_bytes(logL, batch);
+        case ROUTE_FIELD64: return 2 * ((size_t)1 << logL) * sizeof(uint64_t);
+        default: return 0;
+    }
 }
 
 int ntt_poly_multiply_batched_device(const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_ab, int n, uint32_t p, size_t batch,
@@ -571,11 +628,20 @@ int ntt_poly_multiply_batched_device_u64(const uint64_t* d_a, const uint64_t* d_
     if (batch == 0) return NTT_OK;
     Device* dev = nullptr;
     if ((rc = current_device(&dev)) != NTT_OK) return rc;
-    if (direct_path_ok(p, transform_log2(n)))
-        return product_device<uint64_t, uint64_t>(dev, d_a, d_b, d_ab, n, (uint32_t)p, batch, a_stride, b_stride, ab_stride,
-                                                  workspace, workspace_bytes, (hipStream_t)stream);
-    return crt_product_device(dev, d_a, d_b, d_ab, n, p, batch, a_stride, b_stride, ab_stride, workspace, workspace_bytes,
-                              (hipStream_t)stream);
+    std::string why;
+    switch (choose_route(p, (size_t)n, &why)) {
+        case ROUTE_DIRECT32:
+            return product_device<uint64_t, uint64_t>(dev, d_a, d_b, d_ab, n, (uint32_t)p, batch, a_stride, b_stride, ab_stride,
+                                                      workspace, workspace_bytes, (hipStream_t)stream);
+        case ROUTE_CRT:
+            return crt_product_device(dev, d_a, d_b, d_ab, n, p, batch, a_stride, b_stride, ab_stride, workspace, workspace_bytes,
+                                      (hipStream_t)stream);
+        case ROUTE_FIELD64:
+            return field64_product_device(dev, d_a, d_b, d_ab, (size_t)n, p, batch, a_stride, b_stride, ab_stride, workspace,
+                                          workspace_bytes, (hipStream_t)stream);
+        default:
+            return fail(NTT_ERR_MODULUS, why);
+    }
 }
 
 int ntt_crt_merge_device(const uint32_t* d_res, size_t res_stride, uint64_t* d_out, size_t count, uint64_t p, void* stream) {
@@ -624,16 +690,16 @@ int ntt_poly_multiply_batched(const uint32_t* a, const uint32_t* b, uint32_t* ab
 int ntt_poly_multiply_batched_u64(const uint64_t* a, const uint64_t* b, uint64_t* ab, int n, uint64_t p, size_t batch, int n_gpus) {
     int rc = check_args(a, b, ab, n, batch);
     if (rc != NTT_OK) return rc;
-    const bool direct = direct_path_ok(p, transform_log2(n));
-    if (!direct && !crt_bound_ok(n, p))
-        return fail(NTT_ERR_MODULUS, "n*(p-1)^2 exceeds the product of the four CRT primes: result would not be exact");
+    std::string why;
+    const Route route = choose_route(p, (size_t)n, &why);
+    if (route == ROUTE_NONE) return fail(NTT_ERR_MODULUS, why);
     return run_host_sharded<uint64_t>(a, b, ab, n, batch, n_gpus,
         [&](Device* dev, const uint64_t* da, const uint64_t* db, uint64_t* dout, size_t shard) {
-            if (direct)
-                return product_device<uint64_t, uint64_t>(dev, da, db, dout, n, (uint32_t)p, shard, (size_t)n, (size_t)n,
-                                                          (size_t)(2 * n - 1), nullptr, 0, dev->stream);
-            return crt_product_device(dev, da, db, dout, n, p, shard, (size_t)n, (size_t)n, (size_t)(2 * n - 1), nullptr, 0,
-                                      dev->stream);
+            const size_t sn = (size_t)n, so = (size_t)(2 * n - 1);
+            if (route == ROUTE_DIRECT32)
+                return product_device<uint64_t, uint64_t>(dev, da, db, dout, n, (uint32_t)p, shard, sn, sn, so, nullptr, 0, dev->stream);
+            if (route == ROUTE_CRT) return crt_product_device(dev, da, db, dout, n, p, shard, sn, sn, so, nullptr, 0, dev->stream);
+            return field64_product_device(dev, da, db, dout, sn, p, shard, sn, sn, so, nullptr, 0, dev->stream);
         });
 }
 
@@ -758,32 +824,7 @@ int ntt64_poly_multiply_device(const uint64_t* d_a, const uint64_t* d_b, uint64_
     if (rc != NTT_OK) return rc;
     Device* dev = nullptr;
     if ((rc = current_device(&dev)) != NTT_OK) return rc;
-    int logL = ceil_log2(2 * (uint64_t)n - 1);
-    if (logL < 1) logL = 1;
-    Plan64* pl = nullptr;
-    if ((rc = get_plan64(dev, p, logL, &pl)) != NTT_OK) return rc;
-    const size_t L = (size_t)1 << logL, need = 2 * L * sizeof(uint64_t);
-    if (workspace) {
-        if (workspace_bytes < need) return fail(NTT_ERR_WORKSPACE, "workspace too small");
-    } else {
-        if ((rc = dev->work.ensure(need)) != NTT_OK) return rc;
-        workspace = dev->work.ptr;
-    }
-    uint64_t* wa = (uint64_t*)workspace;
-    uint64_t* wb = wa + L;
-    hipStream_t st = (hipStream_t)stream;
-    NTT_LAUNCH_P("k64_load", k64_load, dim3(grid_for(L)), dim3(256), st, d_a, (size_t)0, (uint64_t)n, wa, (uint64_t)L, (uint64_t)1, pl->fc);
-    NTT_LAUNCH_P("k64_load", k64_load, dim3(grid_for(L)), dim3(256), st, d_b, (size_t)0, (uint64_t)n, wb, (uint64_t)L, (uint64_t)1, pl->fc);
-    if ((rc = transform64(*pl, wa, logL, 1, 1, false, st)) != NTT_OK) return rc;
-    if ((rc = transform64(*pl, wb, logL, 1, 1, false, st)) != NTT_OK) return rc;
-    NTT_LAUNCH_P("k64_pointwise", k64_pointwise, dim3(grid_for(L)), dim3(256), st, wa, (const uint64_t*)wb, (uint64_t)L, pl->fc);
-    if ((rc = transform64(*pl, wa, logL, 1, 1, true, st)) != NTT_OK) return rc;
-    const uint64_t Linv = h_powmod((uint64_t)L % p, p - 2, p);
-    const uint64_t scale_m = h_mont64(h_mulmod(Linv, pl->fc.r1, p), p);
-    NTT_LAUNCH_P("k64_finalize", k64_finalize, dim3(grid_for(2 * n - 1)), dim3(256), st, (const uint64_t*)wa, (uint64_t)L, d_out,
-                 (size_t)0, (uint64_t)(2 * n - 1), (uint64_t)1, scale_m, pl->fc);
-    HIP_TRY(hipGetLastError());
-    return NTT_OK;
+    return field64_product_device(dev, d_a, d_b, d_out, n, p, 1, n, n, 2 * n - 1, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int ntt_profile_enable(int on) {
@@ -818,11 +859,13 @@ int ntt_profile_read(char* names, size_t names_len, double* total_ms, int* launc
 int ntt_describe_plan(int n, uint64_t p, char* buf, size_t buf_len) {
     if (!buf || buf_len == 0 || n < 1) return fail(NTT_ERR_ARG, "bad argument");
     const int logL = transform_log2(n);
-    std::string s;
-    const bool direct = direct_path_ok(p, logL);
+    std::string s, why;
+    const Route route = choose_route(p, (size_t)n, &why);
     const char* pipe = logL <= 12 ? "k_small" : logL == 13 ? "k_fused8192" : "k_fwd_strided,k_core_mul,k_inv_strided";
-    if (direct) s = pipe;
-    else s = std::string("4x(") + pipe + "),k_crt_merge";
+    if (route == ROUTE_DIRECT32) s = pipe;
+    else if (route == ROUTE_CRT) s = std::string("4x(") + pipe + "),k_crt_merge";
+    else if (route == ROUTE_FIELD64) s = "k64_load,k64_strided,k64_local,k64_pointwise,k64_finalize";
+    else return fail(NTT_ERR_MODULUS, why);
     snprintf(buf, buf_len, "%s", s.c_str());
     return NTT_OK;
 }

@@ -79,7 +79,7 @@ def test_error_reporting(twin):
     from ntt_amd._binding import NttError
     big = np.ones(1 << 19, dtype=np.uint64)
     with pytest.raises(NttError) as e:
-        twin.multiply_u64(big, big, BIGP)
+        twin.multiply_u64(big, big, 1000000007)   # beyond the CRT bound, and 2^20 does not divide p-1
     assert e.value.status == -2
     with pytest.raises(NttError):
         twin.multiply_batched(np.ones((2, 8), dtype=np.uint32), np.ones((2, 8), dtype=np.uint32), 1000000007)
@@ -133,3 +133,16 @@ def test_explicit_fourstep_matrix_form(twin, oracle):
         want = oracle.crt_ntt_multiply(az, bz, BIGP)[:2 * n - 1]
         assert np.array_equal(poly_multiply_fourstep(twin, a, b, BIGP, torch.device("cpu")), want), n
     assert plan_shape(1 << 28, 8) == (29, 14, 15)
+
+
+def test_route_selection_beyond_the_reference_range(twin):
+    """Lengths above 2^18 and large moduli above the CRT bound go to the 64-bit field (shift property, exact)."""
+    rng = np.random.default_rng(18)
+    for p, n in ((BIGP, 1 << 18), (998244353, 1 << 19)):
+        a = rng.integers(0, p, n, dtype=np.uint64)
+        e = np.zeros(n, dtype=np.uint64); e[5] = 1
+        got = twin.multiply_u64(a, e, p)
+        assert np.array_equal(got[5:5 + n], a) and not got[:5].any() and not got[5 + n:].any()
+    assert twin.describe_plan(1 << 17, BIGP).endswith("k_crt_merge")
+    assert twin.describe_plan(1 << 18, BIGP).startswith("k64_")
+    assert twin.describe_plan(1 << 19, 998244353).startswith("k64_")

@@ -154,6 +154,22 @@ def test_errors_are_reported_not_computed(gpu_lib):
     from ntt_amd._binding import NttError
     big = np.ones(1 << 19, dtype=np.uint64)
     with pytest.raises(NttError):
-        gpu_lib.multiply_u64(big, big, BIGP)     # exceeds the CRT bound
+        gpu_lib.multiply_u64(big, big, 1000000007)     # beyond the CRT bound, and 2^20 does not divide p-1
     with pytest.raises(NttError):
         gpu_lib.multiply_batched(np.ones((2, 8), dtype=np.uint32), np.ones((2, 8), dtype=np.uint32), 1000000007)
+
+
+def test_routes_beyond_the_reference_range(gpu_lib, oracle):
+    """n = 2^18 with the 51-bit modulus (past the four-prime CRT bound) and n = 2^19 with a 32-bit prime (past the
+    2^18 transform limit of the 32-bit kernels) are served by the 64-bit field through the same entry point."""
+    rng = np.random.default_rng(18)
+    for p, n in ((BIGP, 1 << 18), (998244353, 1 << 19)):
+        a = rng.integers(0, p, n, dtype=np.uint64)
+        e = np.zeros(n, dtype=np.uint64); e[5] = 1
+        got = gpu_lib.multiply_u64(a, e, p)
+        assert np.array_equal(got[5:5 + n], a) and not got[:5].any() and not got[5 + n:].any()
+    # and agree with the 32-bit route where both exist: n = 2^17 computed as a 2^18-length zero-extended operand
+    p, n = 998244353, 1 << 17
+    a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
+    az = np.zeros(2 * n, dtype=np.uint64); bz = np.zeros(2 * n, dtype=np.uint64); az[:n] = a; bz[:n] = b
+    assert np.array_equal(gpu_lib.multiply_u64(az, bz, p)[:2 * n - 1], oracle.ntt_multiply(a, b, p))
