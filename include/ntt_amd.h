@@ -129,6 +129,13 @@ size_t ntt64_workspace_bytes(size_t n);
 int ntt64_poly_multiply_device(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n, uint64_t p,
                                void *workspace, size_t workspace_bytes, void *stream);
 
+/* Stand-alone transform in natural order, in place: the reference's `NTT(a, n, invert, p, 3)`
+ * (main_naive.cc:96-137) including its bit-reversal (main_naive.cc:82-95) and, for invert != 0, the
+ * n^-1 scaling (main_naive.cc:131-136).  n a power of two with n | p-1, p < 2^60; values are reduced
+ * mod p on the way in and canonical on the way out.  Host form (one row) and device form (batch rows). */
+int ntt_transform_u64(uint64_t *a, int n, int invert, uint64_t p);
+int ntt_transform_device_u64(uint64_t *d_a, size_t n, size_t batch, int invert, uint64_t p, void *stream);
+
 /* Per-kernel timing for benchmarks (no counterpart in the reference, whose only clock is the
  * chrono pair around the multiply, main_naive.cc:251-261).  While enabled, every kernel launch is
  * bracketed by HIP events on the stream it is launched on.  ntt_profile_read waits for the

@@ -26,6 +26,7 @@ EXPORTS = [
     "ntt_crt_merge_device", "ntt_crt_residue_product_device", "ntt_crt_prime", "ntt_describe_plan",
     "ntt64_transform_device", "ntt64_twiddle_device", "ntt64_pointwise_device", "ntt64_load_device",
     "ntt64_finalize_device", "ntt64_workspace_bytes", "ntt64_poly_multiply_device",
+    "ntt_transform_u64", "ntt_transform_device_u64",
 ]
 
 
@@ -78,6 +79,8 @@ class NttLibrary:
         L.ntt64_finalize_device.argtypes = [vp, sz, vp, sz, sz, sz, u64, ci, ci, vp]; L.ntt64_finalize_device.restype = ci
         L.ntt64_workspace_bytes.argtypes = [sz]; L.ntt64_workspace_bytes.restype = sz
         L.ntt64_poly_multiply_device.argtypes = [vp, vp, vp, sz, u64, vp, sz, vp]; L.ntt64_poly_multiply_device.restype = ci
+        L.ntt_transform_u64.argtypes = [c_u64p, ci, ci, u64]; L.ntt_transform_u64.restype = ci
+        L.ntt_transform_device_u64.argtypes = [vp, sz, sz, ci, u64, vp]; L.ntt_transform_device_u64.restype = ci
 
     # -- helpers ---------------------------------------------------------
     def check(self, status):
@@ -112,6 +115,12 @@ class NttLibrary:
         out = np.zeros(2 * n - 1, dtype=np.uint64)
         self.check(self.lib.ntt_poly_multiply_u64(a.ctypes.data_as(c_u64p), b.ctypes.data_as(c_u64p), out.ctypes.data_as(c_u64p), n, int(p)))
         return out
+
+    def transform_u64(self, a, invert, p):
+        """The reference's NTT(a, n, invert, p, 3): natural order in and out (returns a new array)."""
+        a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+        self.check(self.lib.ntt_transform_u64(a.ctypes.data_as(c_u64p), a.size, int(bool(invert)), int(p)))
+        return a
 
     def multiply_batched(self, a, b, p, n_gpus=0):
         a = np.ascontiguousarray(a, dtype=np.uint32); b = np.ascontiguousarray(b, dtype=np.uint32)

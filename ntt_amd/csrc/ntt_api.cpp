@@ -827,6 +827,63 @@ int ntt64_poly_multiply_device(const uint64_t* d_a, const uint64_t* d_b, uint64_
     return field64_product_device(dev, d_a, d_b, d_out, n, p, 1, n, n, 2 * n - 1, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// ---- stand-alone transforms in natural order (the reference's NTT(), main_naive.cc:96-137) ----
+int ntt_transform_device_u64(uint64_t* d_a, size_t n, size_t batch, int invert, uint64_t p, void* stream) {
+    if (!d_a) return fail(NTT_ERR_ARG, "null pointer");
+    if (n < 1 || (n & (n - 1)) != 0) return fail(NTT_ERR_ARG, "transform length must be a power of two");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    if (batch == 0 || n == 1) {
+        if (n == 1 && batch) {  // length-1 transform is the identity: only canonicalise
+            Device* dev1 = nullptr;
+            if ((rc = current_device(&dev1)) != NTT_OK) return rc;
+            Plan64* pl1 = nullptr;
+            if ((rc = get_plan64(dev1, p, 1, &pl1)) != NTT_OK) return rc;
+            NTT_LAUNCH_P("k64_load", k64_load, dim3(grid_for(batch)), dim3(256), (hipStream_t)stream, (const uint64_t*)d_a, (size_t)1,
+                         (uint64_t)1, d_a, (uint64_t)1, (uint64_t)batch, pl1->fc);
+            HIP_TRY(hipGetLastError());
+        }
+        return NTT_OK;
+    }
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    const int lg = ceil_log2(n);
+    Plan64* pl = nullptr;
+    if ((rc = get_plan64(dev, p, lg, &pl)) != NTT_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t total = (uint64_t)batch * n;
+    NTT_LAUNCH_P("k64_load", k64_load, dim3(grid_for(total)), dim3(256), st, (const uint64_t*)d_a, (size_t)n, (uint64_t)n, d_a,
+                 (uint64_t)n, (uint64_t)batch, pl->fc);
+    uint64_t scale = 1;
+    if (!invert) {
+        if ((rc = transform64(*pl, d_a, lg, 1, batch, false, st)) != NTT_OK) return rc;
+        NTT_LAUNCH_P("k64_bitrev", k64_bitrev, dim3(grid_for(total)), dim3(256), st, d_a, lg, (uint64_t)batch);
+    } else {
+        NTT_LAUNCH_P("k64_bitrev", k64_bitrev, dim3(grid_for(total)), dim3(256), st, d_a, lg, (uint64_t)batch);
+        if ((rc = transform64(*pl, d_a, lg, 1, batch, true, st)) != NTT_OK) return rc;
+        scale = h_powmod((uint64_t)n % p, p - 2, p);   // n^-1, as main_naive.cc:132
+    }
+    NTT_LAUNCH_P("k64_finalize", k64_finalize, dim3(grid_for(total)), dim3(256), st, (const uint64_t*)d_a, (uint64_t)n, d_a, (size_t)n,
+                 (uint64_t)n, (uint64_t)batch, h_mont64(scale, p), pl->fc);
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+
+int ntt_transform_u64(uint64_t* a, int n, int invert, uint64_t p) {
+    if (!a || n < 1) return fail(NTT_ERR_ARG, "bad argument");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    const size_t bytes = (size_t)n * sizeof(uint64_t);
+    if ((rc = dev->io_a.ensure(bytes)) != NTT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(dev->io_a.ptr, a, bytes, hipMemcpyHostToDevice, dev->stream));
+    if ((rc = ntt_transform_device_u64((uint64_t*)dev->io_a.ptr, (size_t)n, 1, invert, p, dev->stream)) != NTT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(a, dev->io_a.ptr, bytes, hipMemcpyDeviceToHost, dev->stream));
+    HIP_TRY(hipStreamSynchronize(dev->stream));
+    return NTT_OK;
+}
+
 int ntt_profile_enable(int on) {
     for (auto& r : g_prof) { hipError_t e = hipEventDestroy(r.e0); e = hipEventDestroy(r.e1); (void)e; }
     g_prof.clear();

@@ -167,6 +167,23 @@ __global__ void __launch_bounds__(256) k64_twiddle(uint64_t* data, uint64_t rows
     data[tid] = f.mulw(f.csub(data[tid], f.B), twiddle_pow(tw, f, e));
 }
 
+// in-place bit-reversal permutation of every row of 2^bits values (the reference's reverse(), main_naive.cc:82-95):
+// thread i swaps with bitrev(i) when i < bitrev(i)
+__global__ void __launch_bounds__(256) k64_bitrev(uint64_t* data, int bits, uint64_t rows) {
+    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t len = (uint64_t)1 << bits;
+    if (tid >= rows * len) return;
+    const uint64_t row = tid >> bits, i = tid & (len - 1);
+    uint64_t rev = 0;
+    for (int b = 0; b < bits; ++b) rev |= ((i >> b) & 1ull) << (bits - 1 - b);
+    if (i < rev) {
+        uint64_t* r = data + row * len;
+        const uint64_t t = r[i];
+        r[i] = r[rev];
+        r[rev] = t;
+    }
+}
+
 // out[row][i] = canonical(data[row][i] * scale) for i < n_out   (scale_m = Montgomery form of the scale)
 __global__ void __launch_bounds__(256) k64_finalize(const uint64_t* data, uint64_t len, uint64_t* out, size_t out_stride,
                                                     uint64_t n_out, uint64_t rows, uint64_t scale_m, Field64Consts fc) {

@@ -146,3 +146,18 @@ def test_route_selection_beyond_the_reference_range(twin):
     assert twin.describe_plan(1 << 17, BIGP).endswith("k_crt_merge")
     assert twin.describe_plan(1 << 18, BIGP).startswith("k64_")
     assert twin.describe_plan(1 << 19, 998244353).startswith("k64_")
+
+
+def test_standalone_transform_matches_reference_ntt(twin, oracle):
+    """ntt_transform_u64 = NTT(a, n, invert, p, 3) of main_naive.cc:96-137 (natural order, inverse scaled by n^-1)."""
+    rng = np.random.default_rng(96)
+    for p in (7340033, 998244353, 1224736769):
+        for n in (1, 2, 4, 64, 1024, 4096, 8192, 32768):
+            x = rng.integers(0, p, n, dtype=np.uint64)
+            fwd = twin.transform_u64(x, False, p)
+            assert np.array_equal(fwd, oracle.ntt(x, False, p)), (p, n)
+            assert np.array_equal(twin.transform_u64(x, True, p), oracle.ntt(x, True, p)), (p, n)
+            assert np.array_equal(twin.transform_u64(fwd, True, p), x)
+    from ntt_amd._binding import NttError
+    with pytest.raises(NttError):
+        twin.transform_u64(np.ones(12, dtype=np.uint64), False, 998244353)   # not a power of two

@@ -82,3 +82,26 @@ def test_long_product_beyond_the_crt_bound(gpu_lib):
         return (ev + sign * od) % p
     for sign in (1, -1):
         assert at(a, sign) * at(b, sign) % p == at(c, sign)
+
+
+@pytest.mark.parametrize("p", [7340033, 998244353, 1224736769])
+def test_standalone_transform_matches_reference_ntt(gpu_lib, oracle, p):
+    rng = np.random.default_rng(p % 31)
+    for n in (1, 2, 8, 512, 4096, 8192, 1 << 16, 1 << 18):
+        x = rng.integers(0, p, n, dtype=np.uint64)
+        fwd = gpu_lib.transform_u64(x, False, p)
+        assert np.array_equal(fwd, oracle.ntt(x, False, p)), n
+        assert np.array_equal(gpu_lib.transform_u64(x, True, p), oracle.ntt(x, True, p)), n
+        assert np.array_equal(gpu_lib.transform_u64(fwd, True, p), x)
+
+
+def test_standalone_transform_batched_device(gpu_lib, oracle):
+    import torch
+    p, n, batch = BIGP, 4096, 5
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, p, (batch, n), dtype=np.uint64)
+    t = torch.from_numpy(x.view(np.int64)).cuda()
+    gpu_lib.check(gpu_lib.lib.ntt_transform_device_u64(t.data_ptr(), n, batch, 0, p, torch.cuda.current_stream().cuda_stream))
+    gpu_lib.check(gpu_lib.lib.ntt_transform_device_u64(t.data_ptr(), n, batch, 1, p, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy().view(np.uint64), x)
