@@ -32,6 +32,7 @@ extern "C" {
 #define NTT_ERR_MODULUS (-2)  /* modulus unsupported for this n (see ntt_last_error) */
 #define NTT_ERR_DEVICE (-3)   /* HIP runtime error or no GPU */
 #define NTT_ERR_WORKSPACE (-4)/* caller workspace too small */
+#define NTT_ERR_IO (-5)       /* data file missing or malformed */
 
 /* Library lifetime.  ntt_init(n_gpus) selects devices 0..n_gpus-1 (n_gpus <= 0: all visible);
  * it replaces the reference's pool/global set-up calls (pthread pool creation main_pthread.cc:755-761,
@@ -135,6 +136,25 @@ int ntt64_poly_multiply_device(const uint64_t *d_a, const uint64_t *d_b, uint64_
  * mod p on the way in and canonical on the way out.  Host form (one row) and device form (batch rows). */
 int ntt_transform_u64(uint64_t *a, int n, int invert, uint64_t p);
 int ntt_transform_device_u64(uint64_t *d_a, size_t n, size_t batch, int invert, uint64_t p, void *stream);
+
+/* Data files of the reference harness, host-only (no GPU needed): `<id>.in` = "n p", n coefficients of a,
+ * n of b, white-space separated (fRead, main_naive.cc:13-30); `<id>.out` = 2n-1 values, one per line
+ * (fCheck main_naive.cc:32-52, fWrite :54-67).  The files are mapped and scanned once instead of going
+ * through iostream extraction.  ntt_io_read_header gives n and p so the caller can size its arrays;
+ * ntt_io_read_in then fills a[0..n-1], b[0..n-1].  flags: NTT_IO_SIDECAR_READ takes the arrays from the
+ * binary sidecar `<path>.bin` when it was made from the text file as it is now (same size and
+ * modification time -- the text file stays the source of truth); NTT_IO_SIDECAR_WRITE (re)creates the
+ * sidecar after a text parse (silently skipped when the directory is read-only).
+ * ntt_io_check_out: 1 when the first `count` values of the file equal ab, 0 when they differ or the file
+ * is short (fCheck's "wrong"), NTT_ERR_IO when it cannot be opened.  ntt_io_read_out reads them instead.
+ * ntt_io_write_out writes `count` values, one per line, byte-identical to fWrite's output. */
+#define NTT_IO_SIDECAR_READ 1
+#define NTT_IO_SIDECAR_WRITE 2
+int ntt_io_read_header(const char *path, int64_t *n, uint64_t *p);
+int ntt_io_read_in(const char *path, uint64_t *a, uint64_t *b, int64_t n, int flags);
+int ntt_io_check_out(const char *path, const uint64_t *ab, int64_t count);
+int ntt_io_read_out(const char *path, uint64_t *ab, int64_t count);
+int ntt_io_write_out(const char *path, const uint64_t *ab, int64_t count);
 
 /* Per-kernel timing for benchmarks (no counterpart in the reference, whose only clock is the
  * chrono pair around the multiply, main_naive.cc:251-261).  While enabled, every kernel launch is

@@ -27,6 +27,8 @@ EXPORTS = [
     "ntt64_transform_device", "ntt64_twiddle_device", "ntt64_pointwise_device", "ntt64_load_device",
     "ntt64_finalize_device", "ntt64_workspace_bytes", "ntt64_poly_multiply_device",
     "ntt_transform_u64", "ntt_transform_device_u64",
+    "ntt_io_read_header", "ntt_io_read_in", "ntt_io_check_out", "ntt_io_read_out", "ntt_io_write_out",
+    "ntt_profile_enable", "ntt_profile_read",
 ]
 
 
@@ -81,6 +83,12 @@ class NttLibrary:
         L.ntt64_poly_multiply_device.argtypes = [vp, vp, vp, sz, u64, vp, sz, vp]; L.ntt64_poly_multiply_device.restype = ci
         L.ntt_transform_u64.argtypes = [c_u64p, ci, ci, u64]; L.ntt_transform_u64.restype = ci
         L.ntt_transform_device_u64.argtypes = [vp, sz, sz, ci, u64, vp]; L.ntt_transform_device_u64.restype = ci
+        i64 = ctypes.c_int64
+        L.ntt_io_read_header.argtypes = [ctypes.c_char_p, ctypes.POINTER(i64), ctypes.POINTER(u64)]; L.ntt_io_read_header.restype = ci
+        L.ntt_io_read_in.argtypes = [ctypes.c_char_p, c_u64p, c_u64p, i64, ci]; L.ntt_io_read_in.restype = ci
+        L.ntt_io_check_out.argtypes = [ctypes.c_char_p, c_u64p, i64]; L.ntt_io_check_out.restype = ci
+        L.ntt_io_read_out.argtypes = [ctypes.c_char_p, c_u64p, i64]; L.ntt_io_read_out.restype = ci
+        L.ntt_io_write_out.argtypes = [ctypes.c_char_p, c_u64p, i64]; L.ntt_io_write_out.restype = ci
 
     # -- helpers ---------------------------------------------------------
     def check(self, status):
@@ -121,6 +129,33 @@ class NttLibrary:
         a = np.ascontiguousarray(a, dtype=np.uint64).copy()
         self.check(self.lib.ntt_transform_u64(a.ctypes.data_as(c_u64p), a.size, int(bool(invert)), int(p)))
         return a
+
+    # -- data files of the reference harness (host-only) --------------------
+    def read_in_file(self, path, sidecar=False):
+        """(n, p, a, b) from `<id>.in`; sidecar=True reuses / refreshes the binary sidecar `<path>.bin`."""
+        n, p = ctypes.c_int64(0), ctypes.c_uint64(0)
+        path_b = os.fsencode(path)
+        self.check(self.lib.ntt_io_read_header(path_b, ctypes.byref(n), ctypes.byref(p)))
+        a = np.empty(n.value, dtype=np.uint64); b = np.empty(n.value, dtype=np.uint64)
+        self.check(self.lib.ntt_io_read_in(path_b, a.ctypes.data_as(c_u64p), b.ctypes.data_as(c_u64p), n.value, 3 if sidecar else 0))
+        return n.value, p.value, a, b
+
+    def read_out_file(self, path, count):
+        ab = np.empty(count, dtype=np.uint64)
+        self.check(self.lib.ntt_io_read_out(os.fsencode(path), ab.ctypes.data_as(c_u64p), count))
+        return ab
+
+    def check_out_file(self, path, ab):
+        """True / False as the reference's fCheck decides; raises when the file cannot be opened."""
+        ab = np.ascontiguousarray(ab, dtype=np.uint64)
+        st = self.lib.ntt_io_check_out(os.fsencode(path), ab.ctypes.data_as(c_u64p), ab.size)
+        if st < 0:
+            self.check(st)
+        return bool(st)
+
+    def write_out_file(self, path, ab):
+        ab = np.ascontiguousarray(ab, dtype=np.uint64)
+        self.check(self.lib.ntt_io_write_out(os.fsencode(path), ab.ctypes.data_as(c_u64p), ab.size))
 
     def multiply_batched(self, a, b, p, n_gpus=0):
         a = np.ascontiguousarray(a, dtype=np.uint32); b = np.ascontiguousarray(b, dtype=np.uint32)

@@ -34,31 +34,24 @@ def poly_multiply_batched_u64(a, b, p, n_gpus=0):
 
 
 # ---- text harness (main_naive.cc:13-67) ------------------------------------
-def read_in_file(path):
-    """`n p` then n coefficients of a and n of b, whitespace separated."""
-    with open(path, "rb") as f:
-        tok = f.read().split()
-    n, p = int(tok[0]), int(tok[1])
-    vals = np.array(tok[2:2 + 2 * n], dtype=np.uint64)
-    if vals.size != 2 * n:
-        raise ValueError(f"{path}: expected {2 * n} coefficients, found {vals.size}")
-    return n, p, vals[:n].copy(), vals[n:].copy()
+# The parsing and formatting run inside the library (mapped file, one scan); these are host-only
+# calls and work without a GPU.
+def read_in_file(path, sidecar=False):
+    """`n p` then n coefficients of a and n of b, whitespace separated -> (n, p, a, b)."""
+    return load_product_library().read_in_file(path, sidecar)
 
 
 def read_out_file(path, n):
-    with open(path, "rb") as f:
-        tok = f.read().split()
-    vals = np.array(tok[:2 * n - 1], dtype=np.uint64)
-    if vals.size != 2 * n - 1:
-        raise ValueError(f"{path}: expected {2 * n - 1} values, found {vals.size}")
-    return vals
+    return load_product_library().read_out_file(path, 2 * n - 1)
+
+
+def check_out_file(path, ab):
+    return load_product_library().check_out_file(path, ab)
 
 
 def write_out_file(path, ab):
     """One value per line, as fWrite does."""
-    with open(path, "w") as f:
-        f.write("\n".join(str(int(v)) for v in ab))
-        f.write("\n")
+    load_product_library().write_out_file(path, ab)
 
 
 def run_harness(data_dir, out_dir=None, ids=range(0, 5), stream=None):
@@ -80,7 +73,7 @@ def run_harness(data_dir, out_dir=None, ids=range(0, 5), stream=None):
         ok = None
         fout = os.path.join(data_dir, f"{i}.out")
         if os.path.exists(fout):
-            ok = bool(np.array_equal(read_out_file(fout, n), ab))
+            ok = check_out_file(fout, ab)
             print("多项式乘法结果正确" if ok else "多项式乘法结果错误", file=stream)
         print(f"average latency for n = {n} p = {p} : {ms:g} (us) ", file=stream)
         if out_dir:

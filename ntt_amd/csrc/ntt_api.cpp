@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -41,6 +42,12 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+}  // namespace
+namespace nttamd {
+void set_error_text(const std::string& s) { g_err = s; }  // for the library's other translation units
+}
+namespace {
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -60,6 +67,23 @@ struct DevBuf {
     }
     void release() {
         if (ptr) { hipError_t e = hipFree(ptr); (void)e; }
+        ptr = nullptr; bytes = 0;
+    }
+};
+
+// page-locked host memory (DMA source/target of the host-pointer entry points)
+struct PinBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return NTT_OK;
+        release();
+        HIP_TRY(hipHostMalloc(&ptr, need, 0));
+        bytes = need;
+        return NTT_OK;
+    }
+    void release() {
+        if (ptr) { hipError_t e = hipHostFree(ptr); (void)e; }
         ptr = nullptr; bytes = 0;
     }
 };
@@ -85,7 +109,8 @@ struct Device {
     std::map<std::pair<uint32_t, int>, std::unique_ptr<Plan>> plans;
     std::map<std::pair<uint64_t, int>, std::unique_ptr<struct Plan64>> plans64;
     DevBuf work;     // library-owned workspace
-    DevBuf io_a, io_b, io_out;  // staging for the host-pointer entry points
+    DevBuf io_a, io_b, io_out;  // device side of the host-pointer entry points
+    PinBuf pin;                 // page-locked staging for the same
 };
 
 std::map<int, std::unique_ptr<Device>> g_devs;  // created on first use of each device
@@ -503,9 +528,15 @@ int check_args(const void* a, const void* b, const void* ab, int n, size_t batch
     return NTT_OK;
 }
 
-// host-pointer driver for one device: H2D, run, D2H (synchronous)
+// Host-pointer driver for one device: H2D, run, D2H.  Calls up to kStageLimit bytes go through the
+// device's page-locked staging buffer (a host memcpy each way, then true asynchronous DMA) -- pageable
+// copies of a few MB cost several times the multiply itself; larger calls use the runtime's own
+// pageable path.  `finish` collects what must run after the stream has been synchronised.
+constexpr size_t kStageLimit = (size_t)64 << 20;
+typedef std::vector<std::function<void()>> FinishList;
+
 template <typename T, typename F>
-int run_host_shard(Device* dev, const T* a, const T* b, T* ab, int n, size_t batch, F&& run) {
+int run_host_shard(Device* dev, const T* a, const T* b, T* ab, int n, size_t batch, F&& run, FinishList& finish) {
     if (batch == 0) return NTT_OK;
     HIP_TRY(hipSetDevice(dev->id));
     const size_t in_bytes = batch * (size_t)n * sizeof(T), out_bytes = batch * (size_t)(2 * n - 1) * sizeof(T);
@@ -513,16 +544,35 @@ int run_host_shard(Device* dev, const T* a, const T* b, T* ab, int n, size_t bat
     if ((rc = dev->io_a.ensure(in_bytes)) != NTT_OK) return rc;
     if ((rc = dev->io_b.ensure(in_bytes)) != NTT_OK) return rc;
     if ((rc = dev->io_out.ensure(out_bytes)) != NTT_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(dev->io_a.ptr, a, in_bytes, hipMemcpyHostToDevice, dev->stream));
-    HIP_TRY(hipMemcpyAsync(dev->io_b.ptr, b, in_bytes, hipMemcpyHostToDevice, dev->stream));
+    const bool staged = 2 * in_bytes + out_bytes <= kStageLimit && dev->pin.ensure(2 * in_bytes + out_bytes) == NTT_OK;
+    char* pa = staged ? (char*)dev->pin.ptr : nullptr;
+    char* pb = staged ? pa + in_bytes : nullptr;
+    char* po = staged ? pb + in_bytes : nullptr;
+    if (staged) {
+        memcpy(pa, a, in_bytes);
+        HIP_TRY(hipMemcpyAsync(dev->io_a.ptr, pa, in_bytes, hipMemcpyHostToDevice, dev->stream));
+        memcpy(pb, b, in_bytes);
+        HIP_TRY(hipMemcpyAsync(dev->io_b.ptr, pb, in_bytes, hipMemcpyHostToDevice, dev->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(dev->io_a.ptr, a, in_bytes, hipMemcpyHostToDevice, dev->stream));
+        HIP_TRY(hipMemcpyAsync(dev->io_b.ptr, b, in_bytes, hipMemcpyHostToDevice, dev->stream));
+    }
     rc = run(dev, (const T*)dev->io_a.ptr, (const T*)dev->io_b.ptr, (T*)dev->io_out.ptr, batch);
     if (rc != NTT_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(ab, dev->io_out.ptr, out_bytes, hipMemcpyDeviceToHost, dev->stream));
+    HIP_TRY(hipMemcpyAsync(staged ? (void*)po : (void*)ab, dev->io_out.ptr, out_bytes, hipMemcpyDeviceToHost, dev->stream));
+    if (staged) finish.push_back([=] { memcpy(ab, po, out_bytes); });
     return NTT_OK;
 }
 
+// 64-bit host arrays whose values all lie below a modulus p < 2^31: narrowed to 32 bits while being staged
+// (half the bytes over PCIe, and the 32-bit kernels' loads), widened again after the copy back.
+// *narrowed = false (nothing enqueued) when a value >= p turns up or the call is too large to stage: the
+// caller then takes the 64-bit path, which reduces arbitrary inputs.
+int run_host_shard_narrow(Device* dev, const uint64_t* a, const uint64_t* b, uint64_t* ab, int n, size_t batch, uint32_t p,
+                          FinishList& finish, bool* narrowed);
+
 template <typename T, typename F>
-int run_host_sharded(const T* a, const T* b, T* ab, int n, size_t batch, int n_gpus, F&& run) {
+int run_host_sharded(const T* a, const T* b, T* ab, int n, size_t batch, int n_gpus, F&& run, uint32_t narrow_p = 0) {
     int rc = do_init(0);
     if (rc != NTT_OK) return rc;
     int G = g_visible;
@@ -532,6 +582,7 @@ int run_host_sharded(const T* a, const T* b, T* ab, int n, size_t batch, int n_g
     HIP_TRY(hipGetDevice(&home));
     const size_t per = (batch + G - 1) / G;
     std::vector<Device*> used;
+    FinishList finish;
     for (int g = 0; g < G; ++g) {
         const size_t lo = (size_t)g * per, hi = lo + per < batch ? lo + per : batch;
         if (lo >= hi) break;
@@ -539,7 +590,15 @@ int run_host_sharded(const T* a, const T* b, T* ab, int n, size_t batch, int n_g
         // a single-device call runs on the caller's current device, a sharded one on devices 0..G-1
         rc = get_device(G == 1 ? home : g, &dev);
         if (rc != NTT_OK) break;
-        rc = run_host_shard(dev, a + lo * n, b + lo * n, ab + lo * (size_t)(2 * n - 1), n, hi - lo, run);
+        bool narrowed = false;
+        if constexpr (sizeof(T) == 8) {
+            if (narrow_p) {
+                rc = run_host_shard_narrow(dev, (const uint64_t*)a + lo * n, (const uint64_t*)b + lo * n,
+                                           (uint64_t*)ab + lo * (size_t)(2 * n - 1), n, hi - lo, narrow_p, finish, &narrowed);
+                if (rc != NTT_OK) break;
+            }
+        }
+        if (!narrowed) rc = run_host_shard(dev, a + lo * n, b + lo * n, ab + lo * (size_t)(2 * n - 1), n, hi - lo, run, finish);
         if (rc != NTT_OK) break;
         used.push_back(dev);
     }
@@ -551,7 +610,41 @@ int run_host_sharded(const T* a, const T* b, T* ab, int n, size_t batch, int n_g
     }
     hipError_t e0 = hipSetDevice(home);
     (void)e0;
+    if (rc == NTT_OK && rc2 == NTT_OK)
+        for (auto& f : finish) f();
     return rc != NTT_OK ? rc : rc2;
+}
+
+int run_host_shard_narrow(Device* dev, const uint64_t* a, const uint64_t* b, uint64_t* ab, int n, size_t batch, uint32_t p,
+                          FinishList& finish, bool* narrowed) {
+    *narrowed = false;
+    if (batch == 0) return NTT_OK;
+    const size_t n_in = batch * (size_t)n, n_out = batch * (size_t)(2 * n - 1);
+    const size_t in_bytes = n_in * sizeof(uint32_t), out_bytes = n_out * sizeof(uint32_t);
+    if (2 * in_bytes + out_bytes > kStageLimit) return NTT_OK;
+    HIP_TRY(hipSetDevice(dev->id));
+    int rc;
+    if ((rc = dev->pin.ensure(2 * in_bytes + out_bytes)) != NTT_OK) return rc;
+    uint32_t* pa = (uint32_t*)dev->pin.ptr;
+    uint32_t* pb = pa + n_in;
+    uint32_t* po = pb + n_in;
+    uint64_t mx = 0;
+    for (size_t i = 0; i < n_in; ++i) { const uint64_t v = a[i]; mx = v > mx ? v : mx; pa[i] = (uint32_t)v; }
+    for (size_t i = 0; i < n_in; ++i) { const uint64_t v = b[i]; mx = v > mx ? v : mx; pb[i] = (uint32_t)v; }
+    if (mx >= p) return NTT_OK;  // unreduced input: the 64-bit loads reduce it
+    if ((rc = dev->io_a.ensure(in_bytes)) != NTT_OK) return rc;
+    if ((rc = dev->io_b.ensure(in_bytes)) != NTT_OK) return rc;
+    if ((rc = dev->io_out.ensure(out_bytes)) != NTT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(dev->io_a.ptr, pa, in_bytes, hipMemcpyHostToDevice, dev->stream));
+    HIP_TRY(hipMemcpyAsync(dev->io_b.ptr, pb, in_bytes, hipMemcpyHostToDevice, dev->stream));
+    rc = product_device<uint32_t, uint32_t>(dev, (const uint32_t*)dev->io_a.ptr, (const uint32_t*)dev->io_b.ptr,
+                                            (uint32_t*)dev->io_out.ptr, n, p, batch, (size_t)n, (size_t)n, (size_t)(2 * n - 1),
+                                            nullptr, 0, dev->stream);
+    if (rc != NTT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(po, dev->io_out.ptr, out_bytes, hipMemcpyDeviceToHost, dev->stream));
+    finish.push_back([=] { for (size_t i = 0; i < n_out; ++i) ab[i] = po[i]; });
+    *narrowed = true;
+    return NTT_OK;
 }
 
 void die(const char* fn) {
@@ -574,7 +667,7 @@ void ntt_shutdown(void) {
         dev->plans.clear();
         for (auto& kv : dev->plans64) kv.second->tables.release();
         dev->plans64.clear();
-        dev->work.release(); dev->io_a.release(); dev->io_b.release(); dev->io_out.release();
+        dev->work.release(); dev->io_a.release(); dev->io_b.release(); dev->io_out.release(); dev->pin.release();
         if (dev->stream) { e = hipStreamDestroy(dev->stream); (void)e; }
     }
     g_devs.clear();
@@ -700,7 +793,7 @@ int ntt_poly_multiply_batched_u64(const uint64_t* a, const uint64_t* b, uint64_t
                 return product_device<uint64_t, uint64_t>(dev, da, db, dout, n, (uint32_t)p, shard, sn, sn, so, nullptr, 0, dev->stream);
             if (route == ROUTE_CRT) return crt_product_device(dev, da, db, dout, n, p, shard, sn, sn, so, nullptr, 0, dev->stream);
             return field64_product_device(dev, da, db, dout, sn, p, shard, sn, sn, so, nullptr, 0, dev->stream);
-        });
+        }, route == ROUTE_DIRECT32 ? (uint32_t)p : 0u);
 }
 
 int ntt_poly_multiply_u64(const uint64_t* a, const uint64_t* b, uint64_t* ab, int n, uint64_t p) {

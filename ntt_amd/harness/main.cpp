@@ -12,37 +12,37 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <fstream>
 #include <iostream>
 #include <string>
 #include <vector>
 
 #include "ntt_amd.h"
 
+// The data files go through the library's mapped-file scanner (ntt_io_*): the reference's iostream
+// extraction (main_naive.cc:13-67) takes tens of milliseconds per 2 MB file, far longer than the GPU multiply.
+// NTT_HARNESS_SIDECAR=1 additionally keeps a binary sidecar <id>.in.bin beside each input.
 static bool read_input(const std::string& path, std::vector<uint64_t>& a, std::vector<uint64_t>& b, int& n, uint64_t& p) {
-    std::ifstream fin(path);
-    if (!fin) return false;
-    if (!(fin >> n >> p) || n < 1) return false;
+    int64_t n64 = 0;
+    if (ntt_io_read_header(path.c_str(), &n64, &p) != NTT_OK || n64 > INT32_MAX / 2) return false;
+    n = (int)n64;
     a.assign(n, 0); b.assign(n, 0);
-    for (int i = 0; i < n; ++i) if (!(fin >> a[i])) return false;
-    for (int i = 0; i < n; ++i) if (!(fin >> b[i])) return false;
+    const char* sc = getenv("NTT_HARNESS_SIDECAR");
+    const int flags = (sc && sc[0] == '1') ? (NTT_IO_SIDECAR_READ | NTT_IO_SIDECAR_WRITE) : 0;
+    if (ntt_io_read_in(path.c_str(), a.data(), b.data(), n, flags) != NTT_OK) {
+        std::cerr << ntt_last_error() << std::endl;
+        return false;
+    }
     return true;
 }
 
 // 1 = equal, 0 = different, -1 = no expected-output file
 static int check_output(const std::string& path, const std::vector<uint64_t>& ab, int n) {
-    std::ifstream fin(path);
-    if (!fin) return -1;
-    for (int i = 0; i < 2 * n - 1; ++i) {
-        uint64_t x;
-        if (!(fin >> x) || x != ab[i]) return 0;
-    }
-    return 1;
+    const int st = ntt_io_check_out(path.c_str(), ab.data(), 2 * (int64_t)n - 1);
+    return st < 0 ? -1 : st;
 }
 
 static void write_output(const std::string& path, const std::vector<uint64_t>& ab, int n) {
-    std::ofstream fout(path);
-    for (int i = 0; i < 2 * n - 1; ++i) fout << ab[i] << '\n';
+    if (ntt_io_write_out(path.c_str(), ab.data(), 2 * (int64_t)n - 1) != NTT_OK) std::cerr << ntt_last_error() << std::endl;
 }
 
 int main(int argc, char** argv) {
@@ -57,15 +57,22 @@ int main(int argc, char** argv) {
         std::cerr << "ntt_init: " << ntt_last_error() << std::endl;
         return 2;
     }
+    const bool verbose = getenv("NTT_HARNESS_VERBOSE") != nullptr;  // per-phase wall times on stderr
+    auto now = [] { return std::chrono::high_resolution_clock::now(); };
+    auto ms_since = [&](std::chrono::high_resolution_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(now() - t).count();
+    };
     int failures = 0, ran = 0;
     for (int id = 0; id <= 4; ++id) {
         std::vector<uint64_t> a, b;
         int n = 0;
         uint64_t p = 0;
         std::string dir;
+        const auto t_read = now();
         for (auto& d : dirs)
             if (read_input(d + std::to_string(id) + ".in", a, b, n, p)) { dir = d; break; }
         if (dir.empty()) continue;
+        const double read_ms = ms_since(t_read);
         std::vector<uint64_t> ab(2 * (size_t)n, 0);
         poly_multiply_u64(a.data(), b.data(), ab.data(), n, p);  // warm-up: plan tables, buffers
         std::fill(ab.begin(), ab.end(), 0);
@@ -73,11 +80,17 @@ int main(int argc, char** argv) {
         poly_multiply_u64(a.data(), b.data(), ab.data(), n, p);
         auto t1 = std::chrono::high_resolution_clock::now();
         std::chrono::duration<double, std::ratio<1, 1000>> ms = t1 - t0;
+        const auto t_check = now();
         int ok = check_output(dir + std::to_string(id) + ".out", ab, n);
+        const double check_ms = ms_since(t_check);
         if (ok == 1) std::cout << "多项式乘法结果正确" << std::endl;
         if (ok == 0) { std::cout << "多项式乘法结果错误" << std::endl; ++failures; }
         std::cout << "average latency for n = " << n << " p = " << p << " : " << ms.count() << " (us) " << std::endl;
+        const auto t_write = now();
         write_output(out_dir + std::to_string(id) + ".out", ab, n);
+        if (verbose)
+            std::cerr << "id " << id << ": read " << read_ms << " ms, multiply " << ms.count() << " ms, check " << check_ms
+                      << " ms, write " << ms_since(t_write) << " ms" << std::endl;
         ++ran;
     }
     ntt_shutdown();

@@ -7,8 +7,25 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def read_in_file(path):
+    """Independent pure-Python reader of the `.in` format (n p, then a, then b), also the check on the library's scanner."""
+    with open(path, "rb") as f:
+        tok = f.read().split()
+    n, p = int(tok[0]), int(tok[1])
+    vals = np.array(tok[2:2 + 2 * n], dtype=np.uint64)
+    assert vals.size == 2 * n, path
+    return n, p, vals[:n].copy(), vals[n:].copy()
+
+
+def read_out_file(path, n):
+    with open(path, "rb") as f:
+        tok = f.read().split()
+    vals = np.array(tok[:2 * n - 1], dtype=np.uint64)
+    assert vals.size == 2 * n - 1, path
+    return vals
+
+
 def iter_golden(max_n=None):
-    from ntt_amd.api import read_in_file, read_out_file
     for f in sorted(os.listdir(GOLDEN)):
         path = os.path.join(GOLDEN, f)
         if f.endswith(".in"):

@@ -43,6 +43,10 @@ class Oracle:
     def _mul(self, fn, a, b, p):
         a, b = _u64(a), _u64(b)
         n = a.size
+        # the transform-based functions share the reference's limit: len = 2n must be a power of two
+        # (main_naive.cc:139-146); other sizes are checked against the schoolbook product instead
+        if fn is not self.lib.oracle_schoolbook_u64 and n & (n - 1):
+            raise ValueError("the transform oracle needs n to be a power of two; use schoolbook_u64")
         out = np.zeros(2 * n - 1, dtype=np.uint64)
         fn(a.ctypes.data_as(u64p), b.ctypes.data_as(u64p), out.ctypes.data_as(u64p), n, int(p))
         return out

@@ -14,7 +14,7 @@ def declared_symbols():
 
 
 def test_header_and_binding_agree():
-    assert declared_symbols() == set(EXPORTS) | {"ntt_profile_enable", "ntt_profile_read"}
+    assert declared_symbols() == set(EXPORTS)
 
 
 def test_library_loads_and_exports_every_declared_symbol():

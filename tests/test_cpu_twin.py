@@ -161,3 +161,20 @@ def test_standalone_transform_matches_reference_ntt(twin, oracle):
     from ntt_amd._binding import NttError
     with pytest.raises(NttError):
         twin.transform_u64(np.ones(12, dtype=np.uint64), False, 998244353)   # not a power of two
+
+
+def test_host_u64_path_narrows_reduced_inputs_and_reduces_the_rest(twin, oracle):
+    # reduced inputs below a 31-bit modulus travel as 32-bit words; a single value >= p sends the call down the
+    # 64-bit loads, which reduce it -- both must give the product of the residues
+    rng = np.random.default_rng(12)
+    for p, n in [(998244353, 1024), (1224736769, 4096), (7340033, 4)]:
+        a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
+        want = oracle.poly_multiply_u64(a, b, p)
+        assert np.array_equal(twin.multiply_u64(a, b, p), want)
+        a2 = a.copy(); a2[n // 2] += np.uint64(p) * np.uint64(3); b2 = b.copy(); b2[0] = np.uint64(2**64 - 1)
+        want2 = oracle.poly_multiply_u64(a2 % np.uint64(p), b2 % np.uint64(p), p)
+        assert np.array_equal(twin.multiply_u64(a2, b2, p), want2)
+        ab = rng.integers(0, p, (3, n), dtype=np.uint64); bb = rng.integers(0, p, (3, n), dtype=np.uint64)
+        got = twin.multiply_batched_u64(ab, bb, p)
+        for r in range(3):
+            assert np.array_equal(got[r], oracle.poly_multiply_u64(ab[r], bb[r], p))

@@ -49,3 +49,24 @@ def test_harness_reports_a_wrong_result(tmp_path):
     (data / "0.out").write_text("4 21 30 48 39 30 9\n")
     r = subprocess.run([HARNESS, str(data), str(outd)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "多项式乘法结果错误" in r.stdout
+
+
+def test_harness_with_binary_sidecar_and_phase_timing(tmp_path):
+    data = tmp_path / "nttdata"; outd = tmp_path / "files"
+    data.mkdir(); outd.mkdir()
+    z1 = np.load(os.path.join(GOLDEN, "nttdata2.npz"))
+    write_case(str(data), 1, int(z1["n"]), int(z1["p"]), z1["a"], z1["b"], z1["out"])
+    env = dict(os.environ, NTT_HARNESS_SIDECAR="1", NTT_HARNESS_VERBOSE="1")
+    log = []
+    for run in range(2):  # the first run parses the text and leaves 1.in.bin, the second reads it
+        r = subprocess.run([HARNESS, str(data), str(outd)], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0 and "多项式乘法结果正确" in r.stdout, r.stdout + r.stderr
+        assert "id 1: read " in r.stderr
+        assert (data / "1.in.bin").exists()
+        log.append(r.stderr)
+    got = np.array((outd / "1.out").read_text().split(), dtype=np.uint64)
+    assert np.array_equal(got, z1["out"].astype(np.uint64))
+    scratch = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(scratch):
+        with open(os.path.join(scratch, "harness_timing.txt"), "w") as f:
+            f.write("run 1 (text parse):\n" + log[0] + "run 2 (sidecar):\n" + log[1])

@@ -173,3 +173,20 @@ def test_routes_beyond_the_reference_range(gpu_lib, oracle):
     a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
     az = np.zeros(2 * n, dtype=np.uint64); bz = np.zeros(2 * n, dtype=np.uint64); az[:n] = a; bz[:n] = b
     assert np.array_equal(gpu_lib.multiply_u64(az, bz, p)[:2 * n - 1], oracle.ntt_multiply(a, b, p))
+
+
+def test_host_u64_path_narrows_reduced_inputs_and_reduces_the_rest(gpu_lib, oracle):
+    rng = np.random.default_rng(12)
+    for p, n in [(998244353, 131072), (1224736769, 4096), (7340033, 4), (469762049, 65536)]:
+        a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
+        want = oracle.poly_multiply_u64(a, b, p)
+        assert np.array_equal(gpu_lib.multiply_u64(a, b, p), want)
+        a2 = a.copy(); a2[n // 2] += np.uint64(p) * np.uint64(3); b2 = b.copy(); b2[0] = np.uint64(2**64 - 1)
+        want2 = oracle.poly_multiply_u64(a2 % np.uint64(p), b2 % np.uint64(p), p)
+        assert np.array_equal(gpu_lib.multiply_u64(a2, b2, p), want2)
+    # a call too large for the page-locked staging buffer takes the pageable path
+    p, n, batch = 998244353, 4096, 2100
+    a = rng.integers(0, p, (batch, n), dtype=np.uint64); b = rng.integers(0, p, (batch, n), dtype=np.uint64)
+    got = gpu_lib.multiply_batched_u64(a, b, p)
+    for r in (0, 1, batch // 2, batch - 1):
+        assert np.array_equal(got[r], oracle.poly_multiply_u64(a[r], b[r], p))
