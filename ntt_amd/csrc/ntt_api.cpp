@@ -564,6 +564,28 @@ int run_host_shard(Device* dev, const T* a, const T* b, T* ab, int n, size_t bat
     return NTT_OK;
 }
 
+// dst[i] = low word of src[i]; returns the largest value seen, saturated to 2^32-1 when any high word is set.
+// Written so that the loop vectorises (no 64-bit compare); the AVX2 clone is picked at load time where available.
+#if defined(__x86_64__) && !defined(NTT_CPU_TWIN) && !defined(__HIP_DEVICE_COMPILE__)
+#define NTT_HOST_SIMD __attribute__((target_clones("avx2", "default")))
+#else
+#define NTT_HOST_SIMD
+#endif
+NTT_HOST_SIMD uint32_t narrow_u64(const uint64_t* src, uint32_t* dst, size_t count) {
+    uint32_t hi_or = 0, mx = 0;
+    for (size_t i = 0; i < count; ++i) {
+        const uint64_t v = src[i];
+        const uint32_t lo = (uint32_t)v;
+        hi_or |= (uint32_t)(v >> 32);
+        mx = lo > mx ? lo : mx;
+        dst[i] = lo;
+    }
+    return hi_or ? 0xFFFFFFFFu : mx;
+}
+NTT_HOST_SIMD void widen_u32(const uint32_t* src, uint64_t* dst, size_t count) {
+    for (size_t i = 0; i < count; ++i) dst[i] = src[i];
+}
+
 // 64-bit host arrays whose values all lie below a modulus p < 2^31: narrowed to 32 bits while being staged
 // (half the bytes over PCIe, and the 32-bit kernels' loads), widened again after the copy back.
 // *narrowed = false (nothing enqueued) when a value >= p turns up or the call is too large to stage: the
@@ -628,10 +650,8 @@ int run_host_shard_narrow(Device* dev, const uint64_t* a, const uint64_t* b, uin
     uint32_t* pa = (uint32_t*)dev->pin.ptr;
     uint32_t* pb = pa + n_in;
     uint32_t* po = pb + n_in;
-    uint64_t mx = 0;
-    for (size_t i = 0; i < n_in; ++i) { const uint64_t v = a[i]; mx = v > mx ? v : mx; pa[i] = (uint32_t)v; }
-    for (size_t i = 0; i < n_in; ++i) { const uint64_t v = b[i]; mx = v > mx ? v : mx; pb[i] = (uint32_t)v; }
-    if (mx >= p) return NTT_OK;  // unreduced input: the 64-bit loads reduce it
+    const uint32_t ma = narrow_u64(a, pa, n_in), mb = narrow_u64(b, pb, n_in);
+    if (ma >= p || mb >= p) return NTT_OK;  // unreduced input: the 64-bit loads reduce it
     if ((rc = dev->io_a.ensure(in_bytes)) != NTT_OK) return rc;
     if ((rc = dev->io_b.ensure(in_bytes)) != NTT_OK) return rc;
     if ((rc = dev->io_out.ensure(out_bytes)) != NTT_OK) return rc;
@@ -642,7 +662,7 @@ int run_host_shard_narrow(Device* dev, const uint64_t* a, const uint64_t* b, uin
                                             nullptr, 0, dev->stream);
     if (rc != NTT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(po, dev->io_out.ptr, out_bytes, hipMemcpyDeviceToHost, dev->stream));
-    finish.push_back([=] { for (size_t i = 0; i < n_out; ++i) ab[i] = po[i]; });
+    finish.push_back([=] { widen_u32(po, ab, n_out); });
     *narrowed = true;
     return NTT_OK;
 }

@@ -178,3 +178,41 @@ def test_host_u64_path_narrows_reduced_inputs_and_reduces_the_rest(twin, oracle)
         got = twin.multiply_batched_u64(ab, bb, p)
         for r in range(3):
             assert np.array_equal(got[r], oracle.poly_multiply_u64(ab[r], bb[r], p))
+
+
+def _bitrev_perm(bits):
+    idx = np.arange(1 << bits)
+    rev = np.zeros_like(idx)
+    for b in range(bits):
+        rev |= ((idx >> b) & 1) << (bits - 1 - b)
+    return rev
+
+
+def check_middle_axis_transform(lib, oracle, to_dev, from_dev, stream, log_root, log_len, inner, outer, p=998244353):
+    """ntt64_transform_device along the middle axis of [outer][2^log_len][inner] against the reference transform
+    applied to every (outer, inner) column; w = root of order 2^log_len derived from the plan's root.  The modulus
+    is a 32-bit prime because the reference transform multiplies in 64 bits (main_naive.cc:116-121)."""
+    rng = np.random.default_rng(log_len * 131 + inner)
+    n = 1 << log_len
+    x = rng.integers(0, p, (outer, n, inner), dtype=np.uint64)
+    dev = to_dev(x)
+    lib.check(lib.lib.ntt64_transform_device(dev.data_ptr(), p, log_root, log_len, inner, outer, 0, stream))
+    got = from_dev(dev).reshape(outer, n, inner) % np.uint64(p)
+    rev = _bitrev_perm(log_len)
+    for o in range(outer):
+        for c in range(inner):
+            want = oracle.ntt(x[o, :, c], False, p)
+            assert np.array_equal(got[o, rev, c], want), (log_len, inner, o, c)
+    lib.check(lib.lib.ntt64_transform_device(dev.data_ptr(), p, log_root, log_len, inner, outer, 1, stream))
+    back = from_dev(dev).reshape(outer, n, inner)
+    ninv = pow(n, p - 2, p)
+    assert np.array_equal((back.astype(object) * ninv % p).astype(np.uint64), x)
+
+
+def test_transform_along_a_strided_axis_tiled_and_register_passes(twin, oracle):
+    import torch
+    to_dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64).copy())
+    from_dev = lambda t: t.numpy().view(np.uint64).copy()
+    # (log_len, inner, outer): odd and even inner extents, tiles of several shapes, register-pass fall-back
+    for log_len, inner, outer in [(10, 6, 2), (9, 8, 1), (11, 16, 1), (5, 3, 3), (13, 1, 2), (14, 1, 1), (4, 40, 2)]:
+        check_middle_axis_transform(twin, oracle, to_dev, from_dev, None, 20, log_len, inner, outer)

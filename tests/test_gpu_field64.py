@@ -105,3 +105,14 @@ def test_standalone_transform_batched_device(gpu_lib, oracle):
     gpu_lib.check(gpu_lib.lib.ntt_transform_device_u64(t.data_ptr(), n, batch, 1, p, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert np.array_equal(t.cpu().numpy().view(np.uint64), x)
+
+
+def test_transform_along_a_strided_axis_tiled_and_register_passes(gpu_lib, oracle):
+    import torch
+    from test_cpu_twin import check_middle_axis_transform
+    to_dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64).copy()).cuda()
+    from_dev = lambda t: t.cpu().numpy().view(np.uint64).copy()
+    st = torch.cuda.current_stream().cuda_stream
+    for log_len, inner, outer in [(10, 6, 2), (9, 8, 1), (11, 16, 1), (5, 3, 3), (13, 1, 2), (14, 1, 1), (4, 40, 2),
+                                  (18, 1, 1), (9, 512, 1), (12, 24, 2)]:
+        check_middle_axis_transform(gpu_lib, oracle, to_dev, from_dev, st, 23, log_len, inner, outer)

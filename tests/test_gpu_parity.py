@@ -190,3 +190,37 @@ def test_host_u64_path_narrows_reduced_inputs_and_reduces_the_rest(gpu_lib, orac
     got = gpu_lib.multiply_batched_u64(a, b, p)
     for r in (0, 1, batch // 2, batch - 1):
         assert np.array_equal(got[r], oracle.poly_multiply_u64(a[r], b[r], p))
+
+
+def test_device_entry_point_can_be_captured_in_a_hip_graph(gpu_lib, oracle):
+    # after one warm-up call (plan tables uploaded) and with a caller workspace the device entry point only
+    # enqueues kernels, so a caller may capture it into a graph and replay it on new data
+    import torch
+    p, n, batch = 998244353, 16384, 3
+    rng = np.random.default_rng(5)
+    L = gpu_lib.lib
+    a = torch.zeros((batch, n), dtype=torch.int32, device="cuda"); b = torch.zeros_like(a)
+    out = torch.zeros((batch, 2 * n), dtype=torch.int32, device="cuda")
+    ws_bytes = L.ntt_workspace_bytes(n, p, batch)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+
+    def enqueue(stream):
+        gpu_lib.check(L.ntt_poly_multiply_batched_device(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, p, batch, n, n, 2 * n,
+                                                          ws.data_ptr(), ws_bytes, stream.cuda_stream))
+    with torch.cuda.stream(side):
+        enqueue(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        enqueue(side)
+    for seed in (1, 2):
+        ha = rng.integers(0, p, (batch, n), dtype=np.uint32); hb = rng.integers(0, p, (batch, n), dtype=np.uint32)
+        a.copy_(torch.from_numpy(ha.view(np.int32))); b.copy_(torch.from_numpy(hb.view(np.int32)))
+        out.zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        res = out.cpu().numpy().view(np.uint32)
+        for r in range(batch):
+            assert np.array_equal(res[r, :2 * n - 1].astype(np.uint64), oracle.ntt_multiply(ha[r], hb[r], p))

@@ -35,6 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-n", type=int, default=28)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--direct-only", action="store_true")
     args = ap.parse_args()
     n = 1 << args.log_n
     lib = load_product_library(); lib.init(0)
@@ -61,6 +62,8 @@ def main():
     print(json.dumps({"workload": f"config5 single GPU direct, n=2^{args.log_n}, p={P}", "ms": dt * 1e3,
                       "butterflies_per_s": 3 * (L // 2) * (args.log_n + 1) / dt, "verified_x=+-1": bool(ok)}), flush=True)
 
+    if args.direct_only:
+        return
     # explicit four-step on the same operands (world = 1): slabs built on the device
     from ntt_amd.fourstep import FourStep
     fs = FourStep(lib, P, n, torch.device("cuda", 0))
