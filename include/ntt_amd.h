@@ -11,7 +11,11 @@
  * p is prime with primitive root 3 and transform length L | p-1, where
  * L = smallest power of two >= 2n-1 (L = 2n when n is a power of two).
  * Moduli above 2^32 -- and any modulus that is not NTT-friendly -- go through
- * four fixed 31-bit NTT primes and a 128-bit CRT merge.
+ * four fixed 31-bit NTT primes and a 128-bit CRT merge (the reference's route,
+ * main_naive.cc:178-230).  Sizes and moduli beyond that basis (n*(p-1)^2 >= 2^118.9
+ * or transform lengths above 2^18) are computed in the 64-bit field of p itself when
+ * p is NTT-friendly, and otherwise through two or three 59-bit NTT primes with a
+ * Garner recombination: every modulus 2 <= p < 2^64 is served.
  *
  * One caller at a time per process (the reference is single-threaded at this
  * boundary too); calls on different devices may not overlap.

@@ -501,11 +501,68 @@ int field64_product_device(Device* dev, const uint64_t* a, const uint64_t* b, ui
     return NTT_OK;
 }
 
+size_t wide_crt_workspace_bytes(size_t n, uint64_t p, size_t batch) {
+    const int logL = ceil_log2(2 * (uint64_t)n - 1) < 1 ? 1 : ceil_log2(2 * (uint64_t)n - 1);
+    const size_t k = (size_t)wide_crt_primes_needed(n, p);
+    return 2 * ((size_t)1 << logL) * sizeof(uint64_t) + k * batch * (2 * n - 1) * sizeof(uint64_t);
+}
+
+int make_wide_crt_consts(uint64_t p, int k, WideCrtConsts* c) {
+    c->k = k;
+    for (int i = 0; i < 3; ++i) {
+        const uint64_t q = kWidePrimes[i];
+        uint64_t inv = q;
+        for (int it = 0; it < 6; ++it) inv *= 2 - q * inv;
+        c->q[i] = q; c->nq[i] = 0 - inv;
+    }
+    const uint64_t q1 = kWidePrimes[0], q2 = kWidePrimes[1], q3 = kWidePrimes[2];
+    c->inv1_m2 = h_mont64(h_powmod(q1 % q2, q2 - 2, q2), q2);
+    c->inv1_m3 = h_mont64(h_powmod(q1 % q3, q3 - 2, q3), q3);
+    c->inv2_m3 = h_mont64(h_powmod(q2 % q3, q3 - 2, q3), q3);
+    c->p = p;
+    c->shift = __builtin_clzll(p);
+    c->d = p << c->shift;
+    c->v = (uint64_t)((~(u128)0) / c->d - ((u128)1 << 64));
+    c->q1_p = q1 % p;
+    c->q12_p = h_mulmod(q1 % p, q2 % p, p);
+    return NTT_OK;
+}
+
+// Any modulus below 2^64, transform lengths up to 2^32: one 64-bit-field product per wide prime, then Garner.
+int wide_crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint64_t p, size_t batch,
+                            size_t sa, size_t sb, size_t so, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int k = wide_crt_primes_needed(n, p);
+    if (k == 0 || p < 2) return fail(NTT_ERR_MODULUS, "n*(p-1)^2 exceeds the product of the three wide CRT primes");
+    const size_t need = wide_crt_workspace_bytes(n, p, batch);
+    if (ws) {
+        if (ws_bytes < need) return fail(NTT_ERR_WORKSPACE, "workspace too small");
+    } else {
+        int rc = dev->work.ensure(need);
+        if (rc != NTT_OK) return rc;
+        ws = dev->work.ptr;
+    }
+    const size_t field_ws = need - (size_t)k * batch * (2 * n - 1) * sizeof(uint64_t);
+    uint64_t* res = (uint64_t*)((char*)ws + field_ws);
+    const size_t count = 2 * n - 1, res_stride = batch * count;
+    for (int i = 0; i < k; ++i) {
+        int rc = field64_product_device(dev, a, b, res + (size_t)i * res_stride, n, kWidePrimes[i], batch, sa, sb, count, ws, field_ws, st);
+        if (rc != NTT_OK) return rc;
+    }
+    WideCrtConsts c;
+    int rc = make_wide_crt_consts(p, k, &c);
+    if (rc != NTT_OK) return rc;
+    NTT_LAUNCH_P("k64_garner", k64_garner, dim3((unsigned)((count + 255) / 256), (unsigned)batch), dim3(256), st, (const uint64_t*)res,
+                 res_stride, out, count, batch, so, count, c);
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+
 // Which arithmetic serves (n, p):
 //   32-bit direct  p < 2^31 NTT-friendly and L <= 2^18 (every case the reference's NTT_multiply covers)
 //   four-prime CRT any p with n*(p-1)^2 below the product of the primes, L <= 2^18 (the reference's route for p > 2^32)
 //   64-bit field   p < 2^60 with L | p-1: lengths and moduli beyond both of the above
-enum Route { ROUTE_DIRECT32, ROUTE_CRT, ROUTE_FIELD64, ROUTE_NONE };
+//   wide CRT       everything else up to L = 2^32: two or three 59-bit NTT primes, Garner recombination
+enum Route { ROUTE_DIRECT32, ROUTE_CRT, ROUTE_FIELD64, ROUTE_WIDECRT, ROUTE_NONE };
 constexpr int MAX_LOG_L32 = 18;
 
 Route choose_route(uint64_t p, size_t n, std::string* why) {
@@ -515,6 +572,7 @@ Route choose_route(uint64_t p, size_t n, std::string* why) {
     if (logL <= MAX_LOG_L32 && n < (1u << 30) && crt_bound_ok((int)n, p)) return ROUTE_CRT;
     std::string w64;
     if (modulus64_ok(p, logL, &w64)) return ROUTE_FIELD64;
+    if (p >= 2 && logL <= 32 && wide_crt_primes_needed(n, p) != 0) return ROUTE_WIDECRT;
     if (why) *why = "no exact route for this modulus and length: the four-prime CRT needs n*(p-1)^2 < 2^118.9 and length <= 2^18; "
                     "the 64-bit field needs " + w64;
     return ROUTE_NONE;
@@ -708,6 +766,7 @@ size_t ntt_workspace_bytes(int n, uint64_t p, size_t batch) {
         case ROUTE_DIRECT32: return pipeline_workspace_bytes(logL, batch);
         case ROUTE_CRT: return crt_workspace_bytes(logL, batch);
         case ROUTE_FIELD64: return 2 * ((size_t)1 << logL) * sizeof(uint64_t);
+        case ROUTE_WIDECRT: return wide_crt_workspace_bytes((size_t)n, p, batch);
         default: return 0;
     }
 }
@@ -752,6 +811,9 @@ int ntt_poly_multiply_batched_device_u64(const uint64_t* d_a, const uint64_t* d_
         case ROUTE_FIELD64:
             return field64_product_device(dev, d_a, d_b, d_ab, (size_t)n, p, batch, a_stride, b_stride, ab_stride, workspace,
                                           workspace_bytes, (hipStream_t)stream);
+        case ROUTE_WIDECRT:
+            return wide_crt_product_device(dev, d_a, d_b, d_ab, (size_t)n, p, batch, a_stride, b_stride, ab_stride, workspace,
+                                           workspace_bytes, (hipStream_t)stream);
         default:
             return fail(NTT_ERR_MODULUS, why);
     }
@@ -812,6 +874,7 @@ int ntt_poly_multiply_batched_u64(const uint64_t* a, const uint64_t* b, uint64_t
             if (route == ROUTE_DIRECT32)
                 return product_device<uint64_t, uint64_t>(dev, da, db, dout, n, (uint32_t)p, shard, sn, sn, so, nullptr, 0, dev->stream);
             if (route == ROUTE_CRT) return crt_product_device(dev, da, db, dout, n, p, shard, sn, sn, so, nullptr, 0, dev->stream);
+            if (route == ROUTE_WIDECRT) return wide_crt_product_device(dev, da, db, dout, sn, p, shard, sn, sn, so, nullptr, 0, dev->stream);
             return field64_product_device(dev, da, db, dout, sn, p, shard, sn, sn, so, nullptr, 0, dev->stream);
         }, route == ROUTE_DIRECT32 ? (uint32_t)p : 0u);
 }
@@ -1035,6 +1098,7 @@ int ntt_describe_plan(int n, uint64_t p, char* buf, size_t buf_len) {
     if (route == ROUTE_DIRECT32) s = pipe;
     else if (route == ROUTE_CRT) s = std::string("4x(") + pipe + "),k_crt_merge";
     else if (route == ROUTE_FIELD64) s = "k64_load,k64_strided,k64_local,k64_pointwise,k64_finalize";
+    else if (route == ROUTE_WIDECRT) s = "k64_load,k64_strided,k64_local,k64_pointwise,k64_finalize,k64_garner";
     else return fail(NTT_ERR_MODULUS, why);
     snprintf(buf, buf_len, "%s", s.c_str());
     return NTT_OK;

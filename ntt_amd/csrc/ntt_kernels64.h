@@ -194,4 +194,65 @@ __global__ void __launch_bounds__(256) k64_finalize(const uint64_t* data, uint64
     out[row * out_stride + i] = f.csub(f.mulw(f.csub(data[row * len + i], f.B), scale_m), f.p);
 }
 
+// ---------------------------------------------------------------------------
+// k64_garner: recombination of residues modulo two or three 59-bit NTT primes into the product coefficient
+// modulo an arbitrary 64-bit p (mixed-radix / Garner form, all arithmetic in 64-bit words):
+//   x = t1 + q1*(t2 + q2*t3),  t1 = r1,  t2 = (r2 - t1)/q1 mod q2,  t3 = ((r3 - t1)/q1 - t2)/q2 mod q3,
+//   out = (t1 + (q1 mod p)*t2 + (q1*q2 mod p)*t3) mod p.
+// The same integer the reference's four-prime sum reconstructs (main_naive.cc:216-223), for operand sizes and
+// moduli whose exact product coefficients no longer fit below the product of its four 31-bit primes.
+// ---------------------------------------------------------------------------
+struct WideCrtConsts {
+    int k;                 // number of primes in use (2 or 3)
+    uint64_t q[3], nq[3];  // primes, -q^-1 mod 2^64
+    uint64_t inv1_m2;      // Montgomery form (mod q2) of q1^-1
+    uint64_t inv1_m3;      // Montgomery form (mod q3) of q1^-1
+    uint64_t inv2_m3;      // Montgomery form (mod q3) of q2^-1
+    uint64_t p, d, v;      // final modulus, p << shift, reciprocal of d (as in the four-prime merge)
+    int shift;
+    uint64_t q1_p, q12_p;  // q1 mod p, q1*q2 mod p
+};
+
+__device__ __forceinline__ uint64_t rem128(uint64_t u1, uint64_t u0, uint64_t d, uint64_t v, int shift) {
+    // (u1:u0) mod (d >> shift) for u1 < (d >> shift); d normalised (Moeller-Granlund 2-by-1 division)
+    if (shift) { u1 = (u1 << shift) | (u0 >> (64 - shift)); u0 <<= shift; }
+    uint64_t q0 = v * u1, q1 = mulhi64(v, u1);
+    q0 += u0;
+    q1 += u1 + (q0 < u0 ? 1u : 0u);
+    q1 += 1;
+    uint64_t r = u0 - q1 * d;
+    if (r > q0) r += d;
+    if (r >= d) r -= d;
+    return r >> shift;
+}
+
+__global__ void __launch_bounds__(256) k64_garner(const uint64_t* res, size_t res_stride, uint64_t* out, size_t count,
+                                                  size_t rows, size_t out_stride, size_t row_stride, WideCrtConsts c) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = blockIdx.y;
+    if (i >= count || row >= rows) return;
+    auto mont = [](uint64_t x, uint64_t wm, uint64_t q, uint64_t nq) -> uint64_t {  // x*w mod q, canonical
+        const uint64_t lo = x * wm, hi = mulhi64(x, wm);
+        const uint64_t m = lo * nq;
+        const uint64_t r = hi + mulhi64(m, q) + (lo != 0 ? 1u : 0u);
+        return r >= q ? r - q : r;
+    };
+    auto csub = [](uint64_t x, uint64_t q) -> uint64_t { return x >= q ? x - q : x; };
+    const uint64_t r1 = res[row * row_stride + i], r2 = res[res_stride + row * row_stride + i];
+    const uint64_t t1 = r1;
+    const uint64_t t2 = mont(r2 - csub(t1, c.q[1]) + c.q[1], c.inv1_m2, c.q[1], c.nq[1]);
+    uint64_t t3 = 0;
+    if (c.k == 3) {
+        const uint64_t r3 = res[2 * res_stride + row * row_stride + i];
+        const uint64_t u = mont(r3 - csub(t1, c.q[2]) + c.q[2], c.inv1_m3, c.q[2], c.nq[2]);
+        t3 = mont(u - csub(t2, c.q[2]) + c.q[2], c.inv2_m3, c.q[2], c.nq[2]);
+    }
+    auto modp = [&](uint64_t x) -> uint64_t { return rem128(0, x, c.d, c.v, c.shift); };
+    auto mulp = [&](uint64_t a, uint64_t b) -> uint64_t { return rem128(mulhi64(a, b), a * b, c.d, c.v, c.shift); };  // a, b < p
+    auto addp = [&](uint64_t a, uint64_t b) -> uint64_t { const uint64_t s = a + b; return (s < a || s >= c.p) ? s - c.p : s; };
+    uint64_t acc = addp(modp(t1), mulp(c.q1_p, modp(t2)));
+    if (c.k == 3) acc = addp(acc, mulp(c.q12_p, modp(t3)));
+    out[row * out_stride + i] = acc;
+}
+
 }  // namespace nttamd

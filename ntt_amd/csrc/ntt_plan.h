@@ -194,4 +194,23 @@ inline bool crt_bound_ok(int n, uint64_t p) {
     return sq * (u128)n < M;
 }
 
+// ---- wide CRT basis: 59-bit primes c*2^32 + 1 for which 3 generates the 2-power subgroup ----
+// Used where neither the four 31-bit primes (product < 2^119, lengths <= 2^21) nor the modulus itself can carry
+// the transform: any p < 2^64, lengths up to 2^32.
+static const uint64_t kWidePrimes[3] = {576460451655712769ull, 576460065108656129ull, 576459820295520257ull};
+
+inline int bit_length(uint64_t x) {
+    int b = 0;
+    while (x) { ++b; x >>= 1; }
+    return b;
+}
+// primes needed so that every coefficient n*(p-1)^2 of the integer product stays below their product
+// (q1*q2 > 2^117, q1*q2*q3 > 2^176); 0 = not even three suffice
+inline int wide_crt_primes_needed(uint64_t n, uint64_t p) {
+    const int bits = bit_length(n) + 2 * bit_length(p - 1);
+    if (bits <= 117) return 2;
+    if (bits <= 176) return 3;
+    return 0;
+}
+
 }  // namespace nttamd

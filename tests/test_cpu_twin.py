@@ -77,10 +77,10 @@ def test_batched_and_i32_entry_points(twin, oracle):
 
 def test_error_reporting(twin):
     from ntt_amd._binding import NttError
-    big = np.ones(1 << 19, dtype=np.uint64)
+    one = np.ones(4, dtype=np.uint64)
     with pytest.raises(NttError) as e:
-        twin.multiply_u64(big, big, 1000000007)   # beyond the CRT bound, and 2^20 does not divide p-1
-    assert e.value.status == -2
+        twin.multiply_u64(one, one, 1)            # no modulus below 2
+    assert e.value.status == -1
     with pytest.raises(NttError):
         twin.multiply_batched(np.ones((2, 8), dtype=np.uint32), np.ones((2, 8), dtype=np.uint32), 1000000007)
     assert twin.describe_plan(131072, 998244353) == "k_fwd_strided,k_core_mul,k_inv_strided"
@@ -216,3 +216,36 @@ def test_transform_along_a_strided_axis_tiled_and_register_passes(twin, oracle):
     # (log_len, inner, outer): odd and even inner extents, tiles of several shapes, register-pass fall-back
     for log_len, inner, outer in [(10, 6, 2), (9, 8, 1), (11, 16, 1), (5, 3, 3), (13, 1, 2), (14, 1, 1), (4, 40, 2)]:
         check_middle_axis_transform(twin, oracle, to_dev, from_dev, None, 20, log_len, inner, outer)
+
+
+def test_wide_crt_route_any_modulus(twin, oracle):
+    """Moduli and sizes that neither the four 31-bit primes nor the modulus itself can carry: two or three 59-bit
+    primes and Garner recombination.  Checked against the schoolbook product in 128-bit arithmetic."""
+    rng = np.random.default_rng(59)
+    cases = [(2**64 - 59, 300),            # largest 64-bit prime: three primes
+             (2**63 + 29, 64), (2**62 - 57, 1000),
+             (2**61 - 1, 257),             # above the 64-bit field's limit
+             (10**18 + 9, 100), (2**64 - 1, 50), (2**64 - 2**32, 33),   # composite and even moduli
+             (2**60 + 33, 1)]
+    for p, n in cases:
+        a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
+        a[0] = p - 1; b[-1] = p - 1
+        assert twin.describe_plan(n, p).endswith("k64_garner"), (p, n)
+        assert np.array_equal(twin.multiply_u64(a, b, p), oracle.schoolbook_u64(a, b, p)), (p, n)
+    # extreme values, every coefficient p-1: the bound n*(p-1)^2 is met with equality in the middle coefficient
+    p, n = 2**64 - 59, 512
+    a = np.full(n, p - 1, dtype=np.uint64)
+    assert np.array_equal(twin.multiply_u64(a, a, p), oracle.schoolbook_u64(a, a, p))
+    # two primes suffice for a 50-bit modulus that is not NTT-friendly at a length above 2^18
+    p, n = 1337006139375617 + 2, 1 << 18     # odd, not of the form c*2^k+1 for large k
+    a = rng.integers(0, p, n, dtype=np.uint64)
+    e = np.zeros(n, dtype=np.uint64); e[3] = 2
+    got = twin.multiply_u64(a, e, p)
+    assert twin.describe_plan(n, p).endswith("k64_garner")
+    assert np.array_equal(got[3:3 + n], (a.astype(object) * 2 % p).astype(np.uint64)) and not got[:3].any()
+    # batched rows
+    p, n = 2**63 + 29, 40
+    ab = rng.integers(0, p, (3, n), dtype=np.uint64); bb = rng.integers(0, p, (3, n), dtype=np.uint64)
+    got = twin.multiply_batched_u64(ab, bb, p)
+    for r in range(3):
+        assert np.array_equal(got[r], oracle.schoolbook_u64(ab[r], bb[r], p))

@@ -152,9 +152,9 @@ def test_device_resident_entry_point_with_strides(gpu_lib, oracle):
 
 def test_errors_are_reported_not_computed(gpu_lib):
     from ntt_amd._binding import NttError
-    big = np.ones(1 << 19, dtype=np.uint64)
+    one = np.ones(4, dtype=np.uint64)
     with pytest.raises(NttError):
-        gpu_lib.multiply_u64(big, big, 1000000007)     # beyond the CRT bound, and 2^20 does not divide p-1
+        gpu_lib.multiply_u64(one, one, 1)              # no modulus below 2
     with pytest.raises(NttError):
         gpu_lib.multiply_batched(np.ones((2, 8), dtype=np.uint32), np.ones((2, 8), dtype=np.uint32), 1000000007)
 
@@ -224,3 +224,24 @@ def test_device_entry_point_can_be_captured_in_a_hip_graph(gpu_lib, oracle):
         res = out.cpu().numpy().view(np.uint32)
         for r in range(batch):
             assert np.array_equal(res[r, :2 * n - 1].astype(np.uint64), oracle.ntt_multiply(ha[r], hb[r], p))
+
+
+def test_wide_crt_route_any_modulus(gpu_lib, oracle):
+    """Same cases as the CPU-twin test of this name, on the GPU, plus a long product that only this route serves
+    (1000000007 is not NTT-friendly and 2^19 coefficients overflow the four-prime bound), cross-checked against
+    the 64-bit-field route on a modulus both can carry."""
+    from test_cpu_twin import test_wide_crt_route_any_modulus as shared
+    shared(gpu_lib, oracle)
+    rng = np.random.default_rng(77)
+    p, n = 1000000007, 1 << 19
+    a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
+    assert gpu_lib.describe_plan(n, p).endswith("k64_garner")
+    got = gpu_lib.multiply_u64(a, b, p)
+    ev = lambda v, s: (int(v[0::2].astype(object).sum()) + s * int(v[1::2].astype(object).sum())) % p
+    for s in (1, -1):
+        assert ev(a, s) * ev(b, s) % p == ev(got, s)
+    assert int(got.max()) < p
+    # head and tail coefficients against direct sums
+    k = 5
+    assert int(got[k]) == sum(int(a[i]) * int(b[k - i]) for i in range(k + 1)) % p
+    assert int(got[2 * n - 2]) == int(a[-1]) * int(b[-1]) % p
