@@ -50,14 +50,17 @@ def cpu_baseline(n, p, min_seconds=12.0, max_reps=100000):
             "host_cpus": os.cpu_count()}
 
 
-def load_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/traffic_*.json)."""
+def load_traffic(kernel, batch):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/traffic_*.json), which was
+    collected at the batch size recorded in it (256 when absent); traffic is proportional to the batch."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")))
     if not files:
         return None
     try:
         with open(files[-1]) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+            d = json.load(f)
+        per_launch = d.get(kernel, {}).get("hbm_bytes_per_launch")
+        return None if per_launch is None else per_launch * batch / d.get("_meta", {}).get("batch", 256)
     except Exception:
         return None
 
@@ -86,9 +89,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % torch.cuda.device_count()  # one rank per GPU; wraps only in single-GPU rehearsals
+    torch.cuda.set_device(device_index)
+    backend = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL carries the barrier and the max-reduce of the clock (the products themselves need no collective);
+        # NTT_BENCH_BACKEND=gloo rehearses the multi-rank logic on a box with fewer GPUs than ranks
+        backend = os.environ.get("NTT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
     n, p, B = args.n, args.p, args.batch
     L = 2 * n
     if args.lib:
@@ -127,10 +138,10 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        elapsed = float(t.item())
 
     # per-kernel durations from the HIP events recorded on the launch stream during the timed steps
     kernels = {}
@@ -173,7 +184,7 @@ def main():
             achieved = alg[dom] / dur / 1e9
             path_gbs = value / world * 96 * n / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(dom),
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(dom, B),
                         "bytes_per_launch": alg[dom], "avg_launch_ms": kernels[dom]["avg_ms"],
                         "bytes_model": "two-pass model, 96*n per product; this kernel's share 56*n (k_core_mul), "
                                        "24*n (k_fwd_strided), 16*n (k_inv_strided)",
