@@ -231,7 +231,11 @@ __device__ __forceinline__ void fwd_column(const TIn* src, int n_valid, uint32_t
 #pragma unroll
     for (int k = 0; k < SG; ++k) wb[0][k] = Tq[(size_t)k * C];
     NTT_FENCE();
+#ifndef NTT_ABLATE_STRIDED_MATH   // diagnostic: memory traffic of the pass without its butterflies
     dif_reg<Q, LZ, PADDED, true>(x, f, fc.rootF, fc.rootFn);
+#else
+    if (PADDED) { for (int r = R / 2; r < R; ++r) x[r] = x[r - R / 2] + 1u; }
+#endif
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
         if (st + 1 < NS) {
@@ -243,10 +247,14 @@ __device__ __forceinline__ void fwd_column(const TIn* src, int n_valid, uint32_t
         for (int k = 0; k < SG; ++k) {
             const int g = st * SG + k;
             const uint4 w = wb[st & 1][k];
+#ifndef NTT_ABLATE_STRIDED_MATH
             if (g) x[4 * g] = f.mulw(x[4 * g], w.x);
             x[4 * g + 1] = f.mulw(x[4 * g + 1], w.y);
             x[4 * g + 2] = f.mulw(x[4 * g + 2], w.z);
             x[4 * g + 3] = f.mulw(x[4 * g + 3], w.w);
+#else
+            x[4 * g] += w.x; x[4 * g + 1] += w.y; x[4 * g + 2] += w.z; x[4 * g + 3] += w.w;
+#endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) dst[(size_t)(4 * g + q) * C + j] = x[4 * g + q];
         }
@@ -283,14 +291,20 @@ __device__ __forceinline__ void inv_column(const uint32_t* src, TOut* dst, int n
         for (int k = 0; k < SG; ++k) {
             const int g = st * SG + k;
             const uint4 w = wb[st & 1][k];
+#ifndef NTT_ABLATE_STRIDED_MATH
             x[4 * g] = g ? f.mulw(x[4 * g], w.x) : (LZ ? csub(x[0], f.B) : x[0]);
             x[4 * g + 1] = f.mulw(x[4 * g + 1], w.y);
             x[4 * g + 2] = f.mulw(x[4 * g + 2], w.z);
             x[4 * g + 3] = f.mulw(x[4 * g + 3], w.w);
+#else
+            x[4 * g] += w.x; x[4 * g + 1] += w.y; x[4 * g + 2] += w.z; x[4 * g + 3] += w.w;
+#endif
         }
         NTT_FENCE();
     }
+#ifndef NTT_ABLATE_STRIDED_MATH
     dit_reg<Q, LZ, true>(x, f, fc.rootI);
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int idx = j + C * r;
