@@ -1,0 +1,24 @@
+import ctypes, sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+from ntt_amd._binding import load_product_library
+lib = load_product_library(); lib.init(0)
+L = lib.lib
+B, n, p = 64, 131072, 1337006139375617
+rng = np.random.default_rng(1)
+a = torch.from_numpy(rng.integers(0, p, (B, n), dtype=np.uint64).view(np.int64)).cuda()
+b = torch.from_numpy(rng.integers(0, p, (B, n), dtype=np.uint64).view(np.int64)).cuda()
+out = torch.zeros((B, 2 * n), dtype=torch.int64, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+def step():
+    lib.check(L.ntt_poly_multiply_batched_device_u64(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, p, B, n, n, 2 * n, None, 0, st))
+for _ in range(3): step()
+torch.cuda.synchronize()
+L.ntt_profile_enable(1)
+for _ in range(5): step()
+torch.cuda.synchronize()
+names = ctypes.create_string_buffer(512); ms = (ctypes.c_double * 16)(); cnt = (ctypes.c_int * 16)()
+L.ntt_profile_read.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+k = L.ntt_profile_read(names, 512, ms, cnt, 16)
+for i, lab in enumerate(names.value.decode().split(",")):
+    print(lab, "avg_us", round(ms[i] / cnt[i] * 1e3, 1), "launches/step", cnt[i] / 5, "us/step", round(ms[i] / 5 * 1e3, 1))
