@@ -1,0 +1,67 @@
+"""Seeded random sweep over sizes, moduli, batch counts and row strides through the device entry points,
+each case against the reference algorithm (power-of-two n) or the 128-bit schoolbook product (other n)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PRIMES32 = [7340033, 104857601, 469762049, 998244353, 1004535809, 1224736769]
+OTHER = [1337006139375617, 1000000007, 2**61 - 1, 2**64 - 59, 4294967311, 65537, 97, 2, 3, 6, 2**32]
+
+
+def expected(oracle, a, b, p):
+    n = a.size
+    if n & (n - 1) == 0 and p in PRIMES32 and 2 * n <= (1 << 18):
+        return oracle.ntt_multiply(a, b, p)
+    return oracle.schoolbook_u64(a, b, p)
+
+
+def test_random_shapes_u64_device(gpu_lib, oracle):
+    import torch
+    rng = np.random.default_rng(20240607)
+    L = gpu_lib.lib
+    st = torch.cuda.current_stream().cuda_stream
+    sizes = [1, 2, 3, 5, 31, 32, 33, 100, 255, 256, 257, 1000, 2047, 2048, 2049, 3000, 4095, 4096, 4097, 6000, 8191, 8192]
+    for case in range(60):
+        n = int(rng.choice(sizes)) if case % 3 else int(rng.integers(1, 3000))
+        p = int(rng.choice(PRIMES32)) if case % 2 else int(OTHER[case // 2 % len(OTHER)])
+        batch = int(rng.integers(1, 4))
+        sa, sb, so = n + int(rng.integers(0, 5)), n + int(rng.integers(0, 5)), 2 * n - 1 + int(rng.integers(0, 5))
+        a = rng.integers(0, p, (batch, sa), dtype=np.uint64); b = rng.integers(0, p, (batch, sb), dtype=np.uint64)
+        if case % 5 == 0:
+            a[:, :n] = p - 1; b[:, :n] = p - 1
+        da = torch.from_numpy(a.view(np.int64)).cuda(); db = torch.from_numpy(b.view(np.int64)).cuda()
+        out = torch.full((batch, so), -1, dtype=torch.int64, device="cuda")
+        gpu_lib.check(L.ntt_poly_multiply_batched_device_u64(da.data_ptr(), db.data_ptr(), out.data_ptr(), n, p, batch, sa, sb, so,
+                                                              None, 0, st))
+        torch.cuda.synchronize()
+        res = out.cpu().numpy().view(np.uint64)
+        for r in range(batch):
+            want = expected(oracle, a[r, :n], b[r, :n], p)
+            assert np.array_equal(res[r, :2 * n - 1], want), (case, n, p, batch, r)
+            assert (res[r, 2 * n - 1:] == np.uint64(2**64 - 1)).all(), "wrote past 2n-1"
+
+
+def test_random_shapes_u32_device(gpu_lib, oracle):
+    import torch
+    rng = np.random.default_rng(77)
+    L = gpu_lib.lib
+    st = torch.cuda.current_stream().cuda_stream
+    for case in range(40):
+        n = int(rng.integers(1, 9000)) if case % 2 else int(2 ** rng.integers(0, 16))
+        p = int(rng.choice(PRIMES32))
+        batch = int(rng.integers(1, 5))
+        sa, sb, so = n + int(rng.integers(0, 3)), n + int(rng.integers(0, 3)), 2 * n - 1 + int(rng.integers(0, 3))
+        a = rng.integers(0, p, (batch, sa), dtype=np.uint32); b = rng.integers(0, p, (batch, sb), dtype=np.uint32)
+        da = torch.from_numpy(a.view(np.int32)).cuda(); db = torch.from_numpy(b.view(np.int32)).cuda()
+        out = torch.full((batch, so), -1, dtype=torch.int32, device="cuda")
+        ws_bytes = L.ntt_workspace_bytes(n, p, batch)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device="cuda")
+        gpu_lib.check(L.ntt_poly_multiply_batched_device(da.data_ptr(), db.data_ptr(), out.data_ptr(), n, p, batch, sa, sb, so,
+                                                          ws.data_ptr(), ws_bytes, st))
+        torch.cuda.synchronize()
+        res = out.cpu().numpy().view(np.uint32)
+        for r in range(batch):
+            want = expected(oracle, a[r, :n].astype(np.uint64), b[r, :n].astype(np.uint64), p)
+            assert np.array_equal(res[r, :2 * n - 1].astype(np.uint64), want), (case, n, p, batch, r)
+            assert (res[r, 2 * n - 1:] == np.uint32(2**32 - 1)).all(), "wrote past 2n-1"
