@@ -164,6 +164,20 @@ def main():
         ah, bh = a.cpu().numpy(), b.cpu().numpy()
         verified = all(np.array_equal(res[r, :2 * n - 1].astype(np.uint64), orc.ntt_multiply(ah[r], bh[r], p)) for r in (0, 1, B - 1))
 
+    # what a plain device-to-device copy reaches on this GPU (read + write bytes per second), outside the timed
+    # region: the practical ceiling to read the 8 TB/s spec peak against
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(1 << 28, dtype=torch.int32, device="cuda"); dst = torch.empty_like(src)  # 1 GiB each
+        dst.copy_(src); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record(); torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * B / (elapsed / args.steps)
@@ -193,6 +207,7 @@ def main():
                         "kernels": {k_: {"avg_ms": v["avg_ms"], "launches": v["launches"],
                                          "GBps_model": alg[k_] / (v["avg_ms"] * 1e-3) / 1e9,
                                          "GBps_moved": moved[k_] / (v["avg_ms"] * 1e-3) / 1e9} for k_, v in kernels.items()},
+                        "measured_copy_GBps": copy_gbs,
                         "path": {"bytes_per_product_model": 96 * n,
                                  "bytes_per_product_moved": sum(moved[k_] for k_ in kernels) // B,
                                  "achieved": path_gbs, "frac": path_gbs / HBM_PEAK_GBS}}
