@@ -78,7 +78,12 @@ struct Field {
 
     NTT_HD uint32_t add(uint32_t u, uint32_t v) const { return csub(u + v, B); }   // u, v in [0,B)
     NTT_HD uint32_t sub_raw(uint32_t u, uint32_t v) const { return u - v + B; }    // (0, 2B), unreduced
-    NTT_HD uint32_t sub(uint32_t u, uint32_t v) const { return csub(u - v + B, B); }
+    // (u - v) mod B for u, v in [0,B): a negative difference wraps to a huge value, so the smaller of d and d + B
+    // is the reduced one -- three plain instructions, no carry flag (the carry form costs a wait state on gfx950)
+    NTT_HD uint32_t sub(uint32_t u, uint32_t v) const {
+        const uint32_t d = u - v, e = d + B;
+        return d < e ? d : e;
+    }
 
     // Gentleman-Sande butterfly, u, v in [0,B) -> [0,B):  u' = u+v, v' = (u-v)*w.  The difference is
     // never formed: (u-v)*w = u*w + v*(-w) is accumulated in 64 bits (two multiply-adds) and reduced
