@@ -98,15 +98,17 @@ def test_shard_range_partitions_exactly():
         shard_range(4, 2, 2)
 
 
-def test_two_gloo_ranks_shard_batch_and_crt_primes(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_ranks_shard_batch_crt_primes_and_fourstep(tmp_path, world):
+    """world = 2: two primes per rank; world = 4: one prime per rank and a 4-way all-to-all in the four-step product."""
     import json
     script = tmp_path / "worker.py"
     script.write_text(f"ROOT = {ROOT!r}\n" + WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), str(script)]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out == {"batched": True, "crt": True, "crt_packaged": True, "fourstep": True, "max": 2.0, "world": 2}
+    assert out == {"batched": True, "crt": True, "crt_packaged": True, "fourstep": True, "max": float(world), "world": world}
