@@ -77,6 +77,43 @@ void oracle_ntt(uint64_t *a, int n, int invert, uint64_t p, uint64_t g) {
     }
 }
 
+/* main.cc:540-566 and 571-630 -- radix-4 form of the same transform.  Values are kept in 64-bit words here
+ * (the reference uses int arrays and 1LL products); p < 2^31 keeps every intermediate below 2^64. */
+void oracle_ntt_base4(uint64_t *a, int n, int invert, uint64_t p, uint64_t g) {
+    int digits = 0;
+    for (int t = n; t > 1; t >>= 2) ++digits;
+    for (int i = 0; i < n; ++i) {            /* base-4 digit reversal */
+        int r = 0, v = i;
+        for (int d = 0; d < digits; ++d) { r = (r << 2) | (v & 3); v >>= 2; }
+        if (i < r) { uint64_t t = a[i]; a[i] = a[r]; a[r] = t; }
+    }
+    for (int len = 4; len <= n; len <<= 2) {
+        uint64_t w1 = invert ? oracle_pow(g, (p - 1) - (p - 1) / (uint64_t)len, p) : oracle_pow(g, (p - 1) / (uint64_t)len, p);
+        uint64_t w2 = w1 * w1 % p, w3 = w2 * w1 % p;
+        int quarter = len >> 2;
+        uint64_t im = oracle_pow(w1, (uint64_t)quarter, p);   /* primitive fourth root of unity */
+        for (int base = 0; base < n; base += len) {
+            uint64_t t1 = 1, t2 = 1, t3 = 1;
+            for (int j = 0; j < quarter; ++j) {
+                uint64_t x0 = a[base + j];
+                uint64_t x1 = a[base + j + quarter] * t1 % p;
+                uint64_t x2 = a[base + j + 2 * quarter] * t2 % p;
+                uint64_t x3 = a[base + j + 3 * quarter] * t3 % p;
+                uint64_t y1 = x1 * im % p, y3 = x3 * im % p;
+                a[base + j] = (x0 + x1 + x2 + x3) % p;
+                a[base + j + quarter] = (x0 + y1 + (p - x2) + (p - y3)) % p;
+                a[base + j + 2 * quarter] = (x0 + (p - x1) + x2 + (p - x3)) % p;
+                a[base + j + 3 * quarter] = (x0 + (p - y1) + (p - x2) + y3) % p;
+                t1 = t1 * w1 % p; t2 = t2 * w2 % p; t3 = t3 * w3 % p;
+            }
+        }
+    }
+    if (invert) {
+        uint64_t ninv = oracle_pow((uint64_t)n % p, p - 2, p);
+        for (int i = 0; i < n; ++i) a[i] = a[i] * ninv % p;
+    }
+}
+
 /* main_naive.cc:139-177 -- zero-pad both inputs to 2n, transform, multiply
  * pointwise, transform back, keep 2n-1 coefficients. */
 void oracle_ntt_multiply(const uint64_t *a, const uint64_t *b, uint64_t *result, int n, uint64_t p) {

@@ -26,6 +26,11 @@ uint64_t oracle_pow(uint64_t base, uint64_t exp, uint64_t mod);
 /* bit-reversal permutation of a[0..n), n = 2^bit (main_naive.cc:82-95) */
 void oracle_reverse(uint64_t *a, int n, int bit);
 
+/* in-place radix-4 DIT transform of n = 4^k values: base-4 digit reversal (main.cc:540-566), then per level
+ * len = 4, 16, ... the four-input butterfly with twiddles w^j, w^2j, w^3j and the fourth root w^(len/4)
+ * (main.cc:571-630); same output as oracle_ntt for the same n, p, g */
+void oracle_ntt_base4(uint64_t *a, int n, int invert, uint64_t p, uint64_t g);
+
 /* in-place radix-2 DIT transform with primitive root g; invert != 0 runs the
  * inverse and scales by n^-1 (main_naive.cc:96-137) */
 void oracle_ntt(uint64_t *a, int n, int invert, uint64_t p, uint64_t g);

@@ -28,6 +28,7 @@ class Oracle:
         L.oracle_ntt_multiply_openmp.restype = None
         L.oracle_openmp_max_threads.restype = ctypes.c_int
         L.oracle_ntt.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64]; L.oracle_ntt.restype = None
+        L.oracle_ntt_base4.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64]; L.oracle_ntt_base4.restype = None
         L.oracle_reverse.argtypes = [u64p, ctypes.c_int, ctypes.c_int]; L.oracle_reverse.restype = None
         L.oracle_poly_multiply_schoolbook.argtypes = [i32p, i32p, i32p, ctypes.c_int, ctypes.c_int]
         L.oracle_poly_multiply_schoolbook.restype = None
@@ -62,6 +63,12 @@ class Oracle:
         out = np.zeros(2 * n - 1, dtype=np.uint64)
         self.lib.oracle_ntt_multiply_openmp(a.ctypes.data_as(u64p), b.ctypes.data_as(u64p), out.ctypes.data_as(u64p), n, int(p), int(threads))
         return out
+
+    def ntt_base4(self, a, invert, p, g=3):
+        a = _u64(a).copy()
+        assert a.size >= 1 and (a.size - 1) & a.size == 0 and (a.size.bit_length() - 1) % 2 == 0, "n must be a power of four"
+        self.lib.oracle_ntt_base4(a.ctypes.data_as(u64p), a.size, int(bool(invert)), int(p), int(g))
+        return a
 
     def ntt(self, a, invert, p, g=3):
         a = _u64(a).copy()
