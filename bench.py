@@ -215,7 +215,7 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                 "config": {"workload": f"batched poly_multiply n={n} p={p}, {B} products per GPU per step, "
-                                       f"inputs/outputs resident in HBM (config 2 of BASELINE.json, batched)",
+                                       f"inputs/outputs resident in HBM (the n = 2^17, p = 998244353 configuration, batched)",
                            "n": n, "p": p, "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}"},
                 "verified_vs_oracle": verified, "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
