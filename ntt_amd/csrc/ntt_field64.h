@@ -15,11 +15,7 @@
 namespace nttamd {
 
 NTT_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umul64hi(a, b);
-#else
     return (uint64_t)(((unsigned __int128)a * b) >> 64);
-#endif
 }
 
 struct Field64Consts {
@@ -41,7 +37,10 @@ struct Field64 {
         return hi + mulhi64(m, p) + (lo != 0 ? 1u : 0u);
     }
     // x < 2^64 (any), wm < 2p Montgomery form of w, with x*wm < 2^64*p: x*w mod p in [0,2p)
-    NTT_HD uint64_t mulw(uint64_t x, uint64_t wm) const { return redc(mulhi64(x, wm), x * wm); }
+    NTT_HD uint64_t mulw(uint64_t x, uint64_t wm) const {
+        const unsigned __int128 t = (unsigned __int128)x * wm;   // one 128-bit product: high and low words share the partial products
+        return redc((uint64_t)(t >> 64), (uint64_t)t);
+    }
     NTT_HD static uint64_t csub(uint64_t x, uint64_t m) { return x >= m ? x - m : x; }
     NTT_HD uint64_t add(uint64_t u, uint64_t v) const { return csub(u + v, B); }
     NTT_HD uint64_t sub_raw(uint64_t u, uint64_t v) const { return u - v + B; }
