@@ -34,6 +34,26 @@ def main(src, tag, batch=256):
             for r in rows[1:]:
                 if short(r[0]):
                     w.writerow(r)
+    # per-launch durations over time since the first launch: the clock transient and the steady state after it
+    traces = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+    if traces:
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(traces[0])):
+            k = short(r["Kernel_Name"])
+            if k:
+                per[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        t0 = min(v[0][0] for v in per.values() if v) if per else 0
+        steady = {}
+        for k, v in per.items():
+            v.sort()
+            early = [d for s_, d in v if s_ - t0 < 30e6]
+            late = [d for s_, d in v if s_ - t0 >= 60e6]
+            steady[k] = {"launches": len(v),
+                         "avg_us_first_30ms": sum(early) / len(early) / 1e3 if early else None,
+                         "max_us_first_30ms": max(early) / 1e3 if early else None,
+                         "avg_us_after_60ms": sum(late) / len(late) / 1e3 if late else None,
+                         "launches_after_60ms": len(late)}
+        json.dump(steady, open(os.path.join(dst, f"{tag}_clock_transient.json"), "w"), indent=1, sort_keys=True)
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
     for path in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(path)):
