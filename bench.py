@@ -39,15 +39,29 @@ def cpu_baseline(n, p, min_seconds=12.0, max_reps=100000):
     want = orc.ntt_multiply(a, b, p)
     got = fn(); fn()                      # warm-up (thread team start-up dominates the first call)
     assert np.array_equal(got, want)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        fn(); reps += 1
-        el = time.perf_counter() - t0
-        if el >= min_seconds or reps >= max_reps:
-            break
-    return {"value": reps / el, "unit": "poly-mults/s", "cores": threads, "kind": kind,
-            "sample": f"{reps} products n={n} p={p} in {el:.1f} s, NTT_multiply_parallel (main_openMP.cc:176-217), {threads} OpenMP threads",
-            "host_cpus": os.cpu_count()}
+    def rate(f, seconds):
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            f(); reps += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or reps >= max_reps:
+                return reps, el
+    reps, el = rate(fn, min_seconds)
+    out = {"value": reps / el, "unit": "poly-mults/s", "cores": threads, "kind": kind,
+           "sample": f"{reps} products n={n} p={p} in {el:.1f} s, NTT_multiply_parallel (main_openMP.cc:176-217), {threads} OpenMP threads",
+           "host_cpus": os.cpu_count()}
+    # the same routine with one thread per core of this box's CPU share (the reference hard-codes 8, main_openMP.cc:15)
+    share = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 8)
+    if share != threads:
+        if ref.openmp is not None:
+            fn2 = lambda: ref.openmp_ntt_multiply(a, b, p, share)
+        else:
+            fn2 = lambda: orc.ntt_multiply_openmp(a, b, p, share)
+        fn2()
+        reps2, el2 = rate(fn2, min_seconds / 2)
+        out["value_all_cores"] = reps2 / el2
+        out["cores_all"] = share
+    return out
 
 
 def load_traffic(kernel, batch):
