@@ -145,6 +145,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if world > 1:
+        # the first collectives create the communicator (seconds): do that before the ramp, so that the barrier in
+        # front of the timed region is a short one and the GPUs enter it warm
+        dist.barrier()
+        tw = torch.zeros(1, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
     # Clock ramp, untimed and declared in the output line: on MI355X the first ~25 ms of a sustained integer load
     # run up to 40 % slower than the steady state that follows (per-launch trace in profiles/), so a short
     # benchmark would time the transient instead of the throughput.
