@@ -142,14 +142,19 @@ struct Field {
     // forward-side value ([0,B)) -> canonical
     NTT_HD uint32_t canon_fwd(uint32_t x) const { return LZ ? csub(x, p) : x; }
 
-    // any 64-bit x -> x mod p in [0,B): hi*R + lo = redc(hi*R2) + redc(lo*R1)
+    // any 64-bit x -> x mod p in [0,B).  lo + hi*2^32 = redc(lo*R + hi*R^2).  LZ (p < 2^30): both products are below
+    // 2^32*p, their sum and the reduction's own addend still fit in 64 bits, and one reduction lands in [0,3p).
+    // Otherwise the two words are reduced separately.  No branch at run time, neither on the data nor on p: a branch
+    // per element ends the basic block and serialises the loads of the column passes behind it.
     NTT_HD uint32_t reduce64(uint64_t x, uint32_t r1, uint32_t r2) const {
-        uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-        uint32_t a = csub(redc_lazy((uint64_t)lo * r1, p, np), p);  // [0,p)
-        if (hi == 0) return a;
-        uint32_t b = csub(redc_lazy((uint64_t)hi * r2, p, np), p);  // [0,p)
-        uint32_t s = csub(a + b, p);
-        return s;
+        const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+        if (LZ) {
+            const uint32_t r = redc_lazy((uint64_t)lo * r1 + (uint64_t)hi * r2, p, np);
+            return csub(r, B);
+        }
+        const uint32_t a = csub(redc_lazy((uint64_t)lo * r1, p, np), p);  // [0,p)
+        const uint32_t b = csub(redc_lazy((uint64_t)hi * r2, p, np), p);  // [0,p)
+        return csub(a + b, p);
     }
 };
 

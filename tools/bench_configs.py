@@ -77,4 +77,4 @@ def config2(n=131072, p=998244353):
 if __name__ == "__main__":
     config2()
     config3(998244353); config3(7340033)
-    config4(1); config4(64)
+    config4(1); config4(64); config4(256)

@@ -1,10 +1,12 @@
+"""Per-kernel times of the four-prime CRT product (n = 2^17, p = 1337006139375617) in steady state.
+usage: python tools/profile_config4.py [batch]"""
 import ctypes, sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, torch
 from ntt_amd._binding import load_product_library
 lib = load_product_library(); lib.init(0)
 L = lib.lib
-B, n, p = 64, 131072, 1337006139375617
+B, n, p = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), 131072, 1337006139375617
 rng = np.random.default_rng(1)
 a = torch.from_numpy(rng.integers(0, p, (B, n), dtype=np.uint64).view(np.int64)).cuda()
 b = torch.from_numpy(rng.integers(0, p, (B, n), dtype=np.uint64).view(np.int64)).cuda()
@@ -12,8 +14,10 @@ out = torch.zeros((B, 2 * n), dtype=torch.int64, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 def step():
     lib.check(L.ntt_poly_multiply_batched_device_u64(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, p, B, n, n, 2 * n, None, 0, st))
-for _ in range(3): step()
-torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 0.15:   # past the clock transient
+    step(); torch.cuda.synchronize()
 L.ntt_profile_enable(1)
 for _ in range(5): step()
 torch.cuda.synchronize()
