@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--n", type=int, default=131072)
     ap.add_argument("--p", type=int, default=998244353)
     ap.add_argument("--batch", type=int, default=256, help="products per GPU per step")
+    ap.add_argument("--input-sets", type=int, default=4,
+                    help="distinct operand sets the steps rotate through, so that no step finds its inputs in the 256 MB "
+                         "Infinity Cache from the step before")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--lib", default=None, help="diagnostic: load this build of the library instead of the shipped one")
@@ -127,15 +130,20 @@ def main():
     lib.init(0)
 
     gen = torch.Generator(device="cuda"); gen.manual_seed(0x5EED0000 + rank)
-    a = torch.randint(0, p, (B, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
-    b = torch.randint(0, p, (B, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32)
+    sets = max(1, args.input_sets)
+    a_sets = [torch.randint(0, p, (B, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32) for _ in range(sets)]
+    b_sets = [torch.randint(0, p, (B, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32) for _ in range(sets)]
+    a, b = a_sets[-1], b_sets[-1]   # the set of the last timed step is the one verified below
     out = torch.zeros((B, L), dtype=torch.int32, device="cuda")
+    turn = [0]
     ws_bytes = lib.lib.ntt_workspace_bytes(n, p, B)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        st = lib.lib.ntt_poly_multiply_batched_device(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, p, B, n, n, L,
+        k = turn[0] % sets
+        turn[0] += 1
+        st = lib.lib.ntt_poly_multiply_batched_device(a_sets[k].data_ptr(), b_sets[k].data_ptr(), out.data_ptr(), n, p, B, n, n, L,
                                                       ws.data_ptr(), ws_bytes, stream)
         lib.check(st)
 
@@ -163,6 +171,7 @@ def main():
             torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
+    turn[0] = sets - (args.steps % sets)   # so that the last timed step uses the last set
     fence()
     if not args.no_kernel_events:
         lib.lib.ntt_profile_enable(1)
@@ -253,7 +262,7 @@ def main():
                 "config": {"workload": f"batched poly_multiply n={n} p={p}, {B} products per GPU per step, "
                                        f"inputs/outputs resident in HBM (the n = 2^17, p = 998244353 configuration, batched)",
                            "n": n, "p": p, "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}"},
-                "ramp_ms_untimed": args.ramp_ms, "verified_vs_oracle": verified, "roofline": roofline}
+                "ramp_ms_untimed": args.ramp_ms, "input_sets": sets, "verified_vs_oracle": verified, "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, p)
         print(json.dumps(line), flush=True)
