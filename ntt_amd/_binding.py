@@ -160,14 +160,14 @@ class NttLibrary:
     def multiply_batched(self, a, b, p, n_gpus=0):
         a = np.ascontiguousarray(a, dtype=np.uint32); b = np.ascontiguousarray(b, dtype=np.uint32)
         batch, n = a.shape
-        out = np.zeros((batch, 2 * n - 1), dtype=np.uint32)
+        out = np.empty((batch, 2 * n - 1), dtype=np.uint32)  # every element is written by the call
         self.check(self.lib.ntt_poly_multiply_batched(a.ctypes.data_as(c_u32p), b.ctypes.data_as(c_u32p), out.ctypes.data_as(c_u32p), n, int(p), batch, int(n_gpus)))
         return out
 
     def multiply_batched_u64(self, a, b, p, n_gpus=0):
         a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)
         batch, n = a.shape
-        out = np.zeros((batch, 2 * n - 1), dtype=np.uint64)
+        out = np.empty((batch, 2 * n - 1), dtype=np.uint64)  # every element is written by the call
         self.check(self.lib.ntt_poly_multiply_batched_u64(a.ctypes.data_as(c_u64p), b.ctypes.data_as(c_u64p), out.ctypes.data_as(c_u64p), n, int(p), batch, int(n_gpus)))
         return out
 
