@@ -249,3 +249,40 @@ def test_wide_crt_route_any_modulus(twin, oracle):
     got = twin.multiply_batched_u64(ab, bb, p)
     for r in range(3):
         assert np.array_equal(got[r], oracle.schoolbook_u64(ab[r], bb[r], p))
+
+
+def check_lifecycle_and_argument_errors(lib, oracle):
+    """Shared by the CPU-twin and the GPU suite: argument checking, empty batches, untouched tail, shutdown and re-use."""
+    import ctypes
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    L = lib.lib
+    p = 998244353
+    a = np.arange(1, 9, dtype=np.uint64); b = np.arange(2, 10, dtype=np.uint64)
+    # the slot after the 2n-1 results is never written (the reference's arrays are zeroed by its caller, main_naive.cc:250)
+    out = np.full(16, 77, dtype=np.uint64)
+    assert L.ntt_poly_multiply_u64(a.ctypes.data_as(u64p), b.ctypes.data_as(u64p), out.ctypes.data_as(u64p), 8, p) == 0
+    assert np.array_equal(out[:15], oracle.ntt_multiply(a, b, p)) and out[15] == 77
+    # argument errors: null pointers, n < 1, negative / zero modulus for the int entry point
+    assert L.ntt_poly_multiply_u64(None, b.ctypes.data_as(u64p), out.ctypes.data_as(u64p), 8, p) == -1
+    assert L.ntt_poly_multiply_u64(a.ctypes.data_as(u64p), b.ctypes.data_as(u64p), out.ctypes.data_as(u64p), 0, p) == -1
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    ai = np.arange(4, dtype=np.int32); oi = np.zeros(8, dtype=np.int32)
+    assert L.ntt_poly_multiply_i32(ai.ctypes.data_as(i32p), ai.ctypes.data_as(i32p), oi.ctypes.data_as(i32p), 4, -5) == -1
+    assert "modulus" in lib.last_error()
+    # an empty batch is a successful no-op
+    z = np.zeros((0, 8), dtype=np.uint32)
+    assert L.ntt_poly_multiply_batched(z.ctypes.data_as(u32p), z.ctypes.data_as(u32p), z.ctypes.data_as(u32p), 8, p, 0, 1) == 0
+    # shutdown releases plans and buffers; the next call sets everything up again
+    first = lib.multiply_u64(a, b, p)
+    lib.shutdown()
+    assert L.ntt_device_count() == 0
+    again = lib.multiply_u64(a, b, p)
+    assert np.array_equal(first, again) and L.ntt_device_count() >= 1
+    big = 1337006139375617
+    x = np.array([big - 1] * 4, dtype=np.uint64)
+    assert np.array_equal(lib.multiply_u64(x, x, big), oracle.crt_ntt_multiply(x, x, big))
+
+
+def test_lifecycle_and_argument_errors(twin, oracle):
+    check_lifecycle_and_argument_errors(twin, oracle)

@@ -245,3 +245,8 @@ def test_wide_crt_route_any_modulus(gpu_lib, oracle):
     k = 5
     assert int(got[k]) == sum(int(a[i]) * int(b[k - i]) for i in range(k + 1)) % p
     assert int(got[2 * n - 2]) == int(a[-1]) * int(b[-1]) % p
+
+
+def test_lifecycle_and_argument_errors(gpu_lib, oracle):
+    from test_cpu_twin import check_lifecycle_and_argument_errors
+    check_lifecycle_and_argument_errors(gpu_lib, oracle)
