@@ -20,8 +20,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <functional>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <memory>
 #include <string>
 #include <vector>
@@ -111,6 +114,14 @@ struct Device {
     DevBuf work;     // library-owned workspace
     DevBuf io_a, io_b, io_out;  // device side of the host-pointer entry points
     PinBuf pin;                 // page-locked staging for the same
+    // two independent staging sets for host-pointer calls too large for `pin`: chunks alternate between them so that
+    // one chunk's copy back overlaps the next chunk's copy in (each set has its own stream, buffers and workspace)
+    struct StageSet {
+        PinBuf pin;
+        DevBuf a, b, out, ws;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+    } stage[2];
 };
 
 std::map<int, std::unique_ptr<Device>> g_devs;  // created on first use of each device
@@ -586,11 +597,157 @@ int check_args(const void* a, const void* b, const void* ab, int n, size_t batch
     return NTT_OK;
 }
 
-// Host-pointer driver for one device: H2D, run, D2H.  Calls up to kStageLimit bytes go through the
+// ---- persistent copy workers ------------------------------------------------------------------
+// The staging copies of large host-pointer calls are memory-bound on the CPU side; a handful of threads that live
+// as long as the library (the analogue of the reference's worker pool, main_pthread.cc:296-441, here only for
+// memcpy) move them at several times the rate of one.
+class CopyPool {
+  public:
+    static CopyPool& get() { static CopyPool* p = new CopyPool(); return *p; }  // never destroyed: workers may outlive main
+    void copy(void* dst, const void* src, size_t bytes) {
+        const size_t piece = (size_t)1 << 20;
+        int parts = (int)((bytes + piece - 1) / piece);
+        if (parts > (int)workers_.size() + 1) parts = (int)workers_.size() + 1;
+        if (parts <= 1) { memcpy(dst, src, bytes); return; }
+        const size_t per = ((bytes / parts) + 63) & ~(size_t)63;
+        run(parts, [=](int i) {
+            const size_t lo = (size_t)i * per;
+            if (lo >= bytes) return;
+            const size_t len = lo + per < bytes ? per : bytes - lo;
+            memcpy((char*)dst + lo, (const char*)src + lo, len);
+        });
+    }
+  private:
+    CopyPool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        const char* omp = getenv("OMP_NUM_THREADS");   // the share of the machine this process was given, where set
+        if (omp && atoi(omp) > 0 && (unsigned)atoi(omp) < hw) hw = (unsigned)atoi(omp);
+        int n = hw > 2 ? (int)hw / 2 - 1 : 0;
+        if (n > 7) n = 7;
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
+        for (auto& t : workers_) t.detach();
+    }
+    void run(int parts, const std::function<void(int)>& fn) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn; parts_ = parts; next_ = 0; remaining_ = parts; ++generation_;
+        }
+        cv_work_.notify_all();
+        work();  // the caller takes its share
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [this] { return remaining_ == 0; });
+        fn_ = nullptr;
+    }
+    void work() {
+        for (;;) {
+            int i;
+            const std::function<void(int)>* fn;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (!fn_ || next_ >= parts_) return;
+                i = next_++; fn = fn_;
+            }
+            (*fn)(i);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--remaining_ == 0) cv_done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_work_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int parts_ = 0, next_ = 0, remaining_ = 0;
+    uint64_t generation_ = 0;
+};
+
+size_t stage_limit_bytes() {  // NTT_STAGE_LIMIT_MB: test hook, lets small calls exercise the chunked path
+    static const size_t v = [] {
+        const char* e = getenv("NTT_STAGE_LIMIT_MB");
+        return (e && atoi(e) > 0) ? (size_t)atoi(e) << 20 : (size_t)64 << 20;
+    }();
+    return v;
+}
+
+// Host-pointer call too large for one staging buffer, on one device: the rows go through in chunks that alternate
+// between two staging sets.  Per chunk: rows -> page-locked memory (copy workers) -> device, product, device ->
+// page-locked memory; the copy out to the caller's array happens when the set comes up for reuse, so it overlaps the
+// other set's transfers.  Synchronous: everything has landed in `ab` on return.
+template <typename T, typename F>
+int run_host_pipelined(Device* dev, const T* a, const T* b, T* ab, int n, uint64_t p, size_t batch, F&& run) {
+    HIP_TRY(hipSetDevice(dev->id));
+    const size_t row_in = (size_t)n * sizeof(T), row_out = (size_t)(2 * n - 1) * sizeof(T);
+    size_t rows = (stage_limit_bytes() / 4) / (2 * row_in + row_out);
+    if (rows < 1) rows = 1;
+    if (rows > batch) rows = batch;
+    const size_t ws_bytes = ntt_workspace_bytes(n, p, rows);
+    int rc;
+    for (auto& s : dev->stage) {
+        if (!s.stream) HIP_TRY(hipStreamCreate(&s.stream));
+        if (!s.done) HIP_TRY(hipEventCreate(&s.done));
+        if ((rc = s.pin.ensure(rows * (2 * row_in + row_out))) != NTT_OK) return rc;
+        if ((rc = s.a.ensure(rows * row_in)) != NTT_OK) return rc;
+        if ((rc = s.b.ensure(rows * row_in)) != NTT_OK) return rc;
+        if ((rc = s.out.ensure(rows * row_out)) != NTT_OK) return rc;
+        if (ws_bytes && (rc = s.ws.ensure(ws_bytes)) != NTT_OK) return rc;
+    }
+    CopyPool& pool = CopyPool::get();
+    struct Pending { T* dst = nullptr; size_t bytes = 0; } pending[2];
+    auto drain = [&](int k) -> int {  // wait for set k's last chunk and hand its results to the caller
+        if (!pending[k].dst) return NTT_OK;
+        HIP_TRY(hipEventSynchronize(dev->stage[k].done));
+        char* po = (char*)dev->stage[k].pin.ptr + 2 * rows * row_in;
+        pool.copy(pending[k].dst, po, pending[k].bytes);
+        pending[k].dst = nullptr;
+        return NTT_OK;
+    };
+    rc = NTT_OK;
+    size_t chunk = 0;
+    for (size_t lo = 0; lo < batch && rc == NTT_OK; lo += rows, ++chunk) {
+        const size_t cnt = lo + rows < batch ? rows : batch - lo;
+        const int k = (int)(chunk & 1);
+        Device::StageSet& s = dev->stage[k];
+        if ((rc = drain(k)) != NTT_OK) break;
+        char* pa = (char*)s.pin.ptr;
+        char* pb = pa + rows * row_in;
+        char* po = pb + rows * row_in;
+        pool.copy(pa, a + lo * n, cnt * row_in);
+        pool.copy(pb, b + lo * n, cnt * row_in);
+        hipError_t e = hipMemcpyAsync(s.a.ptr, pa, cnt * row_in, hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(s.b.ptr, pb, cnt * row_in, hipMemcpyHostToDevice, s.stream);
+        if (e != hipSuccess) { rc = fail(NTT_ERR_DEVICE, std::string("staging copy: ") + hipGetErrorString(e)); break; }
+        rc = run(dev, (const T*)s.a.ptr, (const T*)s.b.ptr, (T*)s.out.ptr, cnt, ws_bytes ? s.ws.ptr : nullptr, ws_bytes, s.stream);
+        if (rc != NTT_OK) break;
+        e = hipMemcpyAsync(po, s.out.ptr, cnt * row_out, hipMemcpyDeviceToHost, s.stream);
+        if (e == hipSuccess) e = hipEventRecord(s.done, s.stream);
+        if (e != hipSuccess) { rc = fail(NTT_ERR_DEVICE, std::string("staging copy: ") + hipGetErrorString(e)); break; }
+        pending[k].dst = ab + lo * (size_t)(2 * n - 1);
+        pending[k].bytes = cnt * row_out;
+    }
+    if (rc != NTT_OK) {  // nothing may still be in flight towards memory the caller owns
+        hipError_t e = hipDeviceSynchronize();
+        (void)e;
+        return rc;
+    }
+    const int first = (int)(chunk & 1);  // the older of the two outstanding chunks
+    if ((rc = drain(first)) != NTT_OK) return rc;
+    return drain(first ^ 1);
+}
+
+// Host-pointer driver for one device: H2D, run, D2H.  Calls up to stage_limit_bytes() bytes go through the
 // device's page-locked staging buffer (a host memcpy each way, then true asynchronous DMA) -- pageable
 // copies of a few MB cost several times the multiply itself; larger calls use the runtime's own
 // pageable path.  `finish` collects what must run after the stream has been synchronised.
-constexpr size_t kStageLimit = (size_t)64 << 20;
 typedef std::vector<std::function<void()>> FinishList;
 
 template <typename T, typename F>
@@ -602,7 +759,7 @@ int run_host_shard(Device* dev, const T* a, const T* b, T* ab, int n, size_t bat
     if ((rc = dev->io_a.ensure(in_bytes)) != NTT_OK) return rc;
     if ((rc = dev->io_b.ensure(in_bytes)) != NTT_OK) return rc;
     if ((rc = dev->io_out.ensure(out_bytes)) != NTT_OK) return rc;
-    const bool staged = 2 * in_bytes + out_bytes <= kStageLimit && dev->pin.ensure(2 * in_bytes + out_bytes) == NTT_OK;
+    const bool staged = 2 * in_bytes + out_bytes <= stage_limit_bytes() && dev->pin.ensure(2 * in_bytes + out_bytes) == NTT_OK;
     char* pa = staged ? (char*)dev->pin.ptr : nullptr;
     char* pb = staged ? pa + in_bytes : nullptr;
     char* po = staged ? pb + in_bytes : nullptr;
@@ -615,7 +772,7 @@ int run_host_shard(Device* dev, const T* a, const T* b, T* ab, int n, size_t bat
         HIP_TRY(hipMemcpyAsync(dev->io_a.ptr, a, in_bytes, hipMemcpyHostToDevice, dev->stream));
         HIP_TRY(hipMemcpyAsync(dev->io_b.ptr, b, in_bytes, hipMemcpyHostToDevice, dev->stream));
     }
-    rc = run(dev, (const T*)dev->io_a.ptr, (const T*)dev->io_b.ptr, (T*)dev->io_out.ptr, batch);
+    rc = run(dev, (const T*)dev->io_a.ptr, (const T*)dev->io_b.ptr, (T*)dev->io_out.ptr, batch, nullptr, (size_t)0, dev->stream);
     if (rc != NTT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(staged ? (void*)po : (void*)ab, dev->io_out.ptr, out_bytes, hipMemcpyDeviceToHost, dev->stream));
     if (staged) finish.push_back([=] { memcpy(ab, po, out_bytes); });
@@ -652,7 +809,7 @@ int run_host_shard_narrow(Device* dev, const uint64_t* a, const uint64_t* b, uin
                           FinishList& finish, bool* narrowed);
 
 template <typename T, typename F>
-int run_host_sharded(const T* a, const T* b, T* ab, int n, size_t batch, int n_gpus, F&& run, uint32_t narrow_p = 0) {
+int run_host_sharded(const T* a, const T* b, T* ab, int n, size_t batch, int n_gpus, F&& run, uint64_t p, uint32_t narrow_p = 0) {
     int rc = do_init(0);
     if (rc != NTT_OK) return rc;
     int G = g_visible;
@@ -660,6 +817,11 @@ int run_host_sharded(const T* a, const T* b, T* ab, int n, size_t batch, int n_g
     if ((size_t)G > batch) G = batch ? (int)batch : 1;
     int home = 0;
     HIP_TRY(hipGetDevice(&home));
+    if (G == 1 && batch * ((size_t)n * 2 + (size_t)(2 * n - 1)) * sizeof(T) > stage_limit_bytes()) {
+        Device* dev = nullptr;
+        if ((rc = get_device(home, &dev)) != NTT_OK) return rc;
+        return run_host_pipelined(dev, a, b, ab, n, p, batch, run);
+    }
     const size_t per = (batch + G - 1) / G;
     std::vector<Device*> used;
     FinishList finish;
@@ -701,7 +863,7 @@ int run_host_shard_narrow(Device* dev, const uint64_t* a, const uint64_t* b, uin
     if (batch == 0) return NTT_OK;
     const size_t n_in = batch * (size_t)n, n_out = batch * (size_t)(2 * n - 1);
     const size_t in_bytes = n_in * sizeof(uint32_t), out_bytes = n_out * sizeof(uint32_t);
-    if (2 * in_bytes + out_bytes > kStageLimit) return NTT_OK;
+    if (2 * in_bytes + out_bytes > stage_limit_bytes()) return NTT_OK;
     HIP_TRY(hipSetDevice(dev->id));
     int rc;
     if ((rc = dev->pin.ensure(2 * in_bytes + out_bytes)) != NTT_OK) return rc;
@@ -746,6 +908,11 @@ void ntt_shutdown(void) {
         for (auto& kv : dev->plans64) kv.second->tables.release();
         dev->plans64.clear();
         dev->work.release(); dev->io_a.release(); dev->io_b.release(); dev->io_out.release(); dev->pin.release();
+        for (auto& s : dev->stage) {
+            s.pin.release(); s.a.release(); s.b.release(); s.out.release(); s.ws.release();
+            if (s.stream) { e = hipStreamDestroy(s.stream); (void)e; s.stream = nullptr; }
+            if (s.done) { e = hipEventDestroy(s.done); (void)e; s.done = nullptr; }
+        }
         if (dev->stream) { e = hipStreamDestroy(dev->stream); (void)e; }
     }
     g_devs.clear();
@@ -856,10 +1023,11 @@ int ntt_poly_multiply_batched(const uint32_t* a, const uint32_t* b, uint32_t* ab
         return fail(NTT_ERR_MODULUS, "32-bit batched path needs an NTT-friendly modulus: " + why);
     }
     return run_host_sharded<uint32_t>(a, b, ab, n, batch, n_gpus,
-        [&](Device* dev, const uint32_t* da, const uint32_t* db, uint32_t* dout, size_t shard) {
+        [&](Device* dev, const uint32_t* da, const uint32_t* db, uint32_t* dout, size_t shard, void* ws, size_t ws_bytes,
+            hipStream_t st) {
             return product_device<uint32_t, uint32_t>(dev, da, db, dout, n, p, shard, (size_t)n, (size_t)n,
-                                                      (size_t)(2 * n - 1), nullptr, 0, dev->stream);
-        });
+                                                      (size_t)(2 * n - 1), ws, ws_bytes, st);
+        }, (uint64_t)p);
 }
 
 int ntt_poly_multiply_batched_u64(const uint64_t* a, const uint64_t* b, uint64_t* ab, int n, uint64_t p, size_t batch, int n_gpus) {
@@ -869,14 +1037,15 @@ int ntt_poly_multiply_batched_u64(const uint64_t* a, const uint64_t* b, uint64_t
     const Route route = choose_route(p, (size_t)n, &why);
     if (route == ROUTE_NONE) return fail(NTT_ERR_MODULUS, why);
     return run_host_sharded<uint64_t>(a, b, ab, n, batch, n_gpus,
-        [&](Device* dev, const uint64_t* da, const uint64_t* db, uint64_t* dout, size_t shard) {
+        [&](Device* dev, const uint64_t* da, const uint64_t* db, uint64_t* dout, size_t shard, void* ws, size_t ws_bytes,
+            hipStream_t st) {
             const size_t sn = (size_t)n, so = (size_t)(2 * n - 1);
             if (route == ROUTE_DIRECT32)
-                return product_device<uint64_t, uint64_t>(dev, da, db, dout, n, (uint32_t)p, shard, sn, sn, so, nullptr, 0, dev->stream);
-            if (route == ROUTE_CRT) return crt_product_device(dev, da, db, dout, n, p, shard, sn, sn, so, nullptr, 0, dev->stream);
-            if (route == ROUTE_WIDECRT) return wide_crt_product_device(dev, da, db, dout, sn, p, shard, sn, sn, so, nullptr, 0, dev->stream);
-            return field64_product_device(dev, da, db, dout, sn, p, shard, sn, sn, so, nullptr, 0, dev->stream);
-        }, route == ROUTE_DIRECT32 ? (uint32_t)p : 0u);
+                return product_device<uint64_t, uint64_t>(dev, da, db, dout, n, (uint32_t)p, shard, sn, sn, so, ws, ws_bytes, st);
+            if (route == ROUTE_CRT) return crt_product_device(dev, da, db, dout, n, p, shard, sn, sn, so, ws, ws_bytes, st);
+            if (route == ROUTE_WIDECRT) return wide_crt_product_device(dev, da, db, dout, sn, p, shard, sn, sn, so, ws, ws_bytes, st);
+            return field64_product_device(dev, da, db, dout, sn, p, shard, sn, sn, so, ws, ws_bytes, st);
+        }, p, route == ROUTE_DIRECT32 ? (uint32_t)p : 0u);
 }
 
 int ntt_poly_multiply_u64(const uint64_t* a, const uint64_t* b, uint64_t* ab, int n, uint64_t p) {

@@ -2,6 +2,8 @@
 HIP stand-in (tests/cpu_twin) must reproduce the oracle bit for bit.  This exercises plan building,
 dispatch by size and modulus, twiddle tables, the LDS slot mapping, the lazy-range bounds and the
 128-bit CRT merge -- everything except the GPU code generation itself (covered by the -m gpu tests)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -286,3 +288,43 @@ def check_lifecycle_and_argument_errors(lib, oracle):
 
 def test_lifecycle_and_argument_errors(twin, oracle):
     check_lifecycle_and_argument_errors(twin, oracle)
+
+
+PIPELINED_WORKER = r'''
+import os, sys
+import os
+
+import numpy as np
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from ntt_amd._binding import NttLibrary
+from oracle_binding import Oracle
+lib = NttLibrary(LIB); orc = Oracle()
+rng = np.random.default_rng(8)
+p, n, batch = 998244353, 2048, 43          # 1.4 MB of rows against a 1 MB limit: chunks of 8 rows, a ragged last one
+a = rng.integers(0, p, (batch, n), dtype=np.uint32); b = rng.integers(0, p, (batch, n), dtype=np.uint32)
+got = lib.multiply_batched(a, b, p, 1)
+ok = all(np.array_equal(got[r].astype(np.uint64), orc.ntt_multiply(a[r], b[r], p)) for r in range(batch))
+P, n2, batch2 = 1337006139375617, 1024, 21  # 64-bit rows through the four-prime route, workspace per staging set
+A = rng.integers(0, P, (batch2, n2), dtype=np.uint64); B = rng.integers(0, P, (batch2, n2), dtype=np.uint64)
+got2 = lib.multiply_batched_u64(A, B, P, 1)
+ok2 = all(np.array_equal(got2[r], orc.crt_ntt_multiply(A[r], B[r], P)) for r in range(batch2))
+one = lib.multiply_batched(a[:1], b[:1], p, 1)   # small call afterwards: single-buffer path again
+print("RESULT", ok, ok2, bool(np.array_equal(one[0], got[0])))
+'''
+
+
+def run_pipelined_worker(lib_path, tmp_path):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "pipelined.py"
+    script.write_text(f"ROOT = {root!r}\nLIB = {lib_path!r}\n" + PIPELINED_WORKER)
+    env = dict(os.environ, NTT_STAGE_LIMIT_MB="1")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RESULT True True True" in r.stdout, r.stdout[-500:]
+
+
+def test_large_host_calls_go_through_in_chunks(twin, tmp_path):
+    """Host-pointer calls beyond the staging limit (lowered here by the test hook) alternate between two staging sets."""
+    run_pipelined_worker(twin.path, tmp_path)

@@ -250,3 +250,8 @@ def test_wide_crt_route_any_modulus(gpu_lib, oracle):
 def test_lifecycle_and_argument_errors(gpu_lib, oracle):
     from test_cpu_twin import check_lifecycle_and_argument_errors
     check_lifecycle_and_argument_errors(gpu_lib, oracle)
+
+
+def test_large_host_calls_go_through_in_chunks(gpu_lib, tmp_path):
+    from test_cpu_twin import run_pipelined_worker
+    run_pipelined_worker(gpu_lib.path, tmp_path)
