@@ -604,8 +604,7 @@ int check_args(const void* a, const void* b, const void* ab, int n, size_t batch
 class CopyPool {
   public:
     static CopyPool& get() { static CopyPool* p = new CopyPool(); return *p; }  // never destroyed: workers may outlive main
-    void copy(void* dst, const void* src, size_t bytes) {
-        const size_t piece = (size_t)1 << 20;
+    void copy(void* dst, const void* src, size_t bytes, size_t piece = (size_t)1 << 20) {
         int parts = (int)((bytes + piece - 1) / piece);
         if (parts > (int)workers_.size() + 1) parts = (int)workers_.size() + 1;
         if (parts <= 1) { memcpy(dst, src, bytes); return; }
@@ -764,9 +763,10 @@ int run_host_shard(Device* dev, const T* a, const T* b, T* ab, int n, size_t bat
     char* pb = staged ? pa + in_bytes : nullptr;
     char* po = staged ? pb + in_bytes : nullptr;
     if (staged) {
-        memcpy(pa, a, in_bytes);
+        CopyPool& pool = CopyPool::get();
+        pool.copy(pa, a, in_bytes, (size_t)512 << 10);
         HIP_TRY(hipMemcpyAsync(dev->io_a.ptr, pa, in_bytes, hipMemcpyHostToDevice, dev->stream));
-        memcpy(pb, b, in_bytes);
+        pool.copy(pb, b, in_bytes, (size_t)512 << 10);
         HIP_TRY(hipMemcpyAsync(dev->io_b.ptr, pb, in_bytes, hipMemcpyHostToDevice, dev->stream));
     } else {
         HIP_TRY(hipMemcpyAsync(dev->io_a.ptr, a, in_bytes, hipMemcpyHostToDevice, dev->stream));
@@ -775,7 +775,7 @@ int run_host_shard(Device* dev, const T* a, const T* b, T* ab, int n, size_t bat
     rc = run(dev, (const T*)dev->io_a.ptr, (const T*)dev->io_b.ptr, (T*)dev->io_out.ptr, batch, nullptr, (size_t)0, dev->stream);
     if (rc != NTT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(staged ? (void*)po : (void*)ab, dev->io_out.ptr, out_bytes, hipMemcpyDeviceToHost, dev->stream));
-    if (staged) finish.push_back([=] { memcpy(ab, po, out_bytes); });
+    if (staged) finish.push_back([=] { CopyPool::get().copy(ab, po, out_bytes, (size_t)512 << 10); });
     return NTT_OK;
 }
 
