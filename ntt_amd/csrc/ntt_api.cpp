@@ -616,6 +616,19 @@ class CopyPool {
             memcpy((char*)dst + lo, (const char*)src + lo, len);
         });
     }
+    // fn(part, lo, hi) over [0, count) cut into at most workers+1 ranges of at least `grain` items
+    void for_range(size_t count, size_t grain, const std::function<void(int, size_t, size_t)>& fn) {
+        int parts = (int)((count + grain - 1) / grain);
+        if (parts > (int)workers_.size() + 1) parts = (int)workers_.size() + 1;
+        if (parts <= 1) { fn(0, 0, count); return; }
+        const size_t per = ((count / parts) + 15) & ~(size_t)15;
+        run(parts, [&](int i) {
+            const size_t lo = (size_t)i * per;
+            if (lo >= count) return;
+            fn(i, lo, lo + per < count ? lo + per : count);
+        });
+    }
+    int max_parts() const { return (int)workers_.size() + 1; }
   private:
     CopyPool() {
         unsigned hw = std::thread::hardware_concurrency();
@@ -870,8 +883,15 @@ int run_host_shard_narrow(Device* dev, const uint64_t* a, const uint64_t* b, uin
     uint32_t* pa = (uint32_t*)dev->pin.ptr;
     uint32_t* pb = pa + n_in;
     uint32_t* po = pb + n_in;
-    const uint32_t ma = narrow_u64(a, pa, n_in), mb = narrow_u64(b, pb, n_in);
-    if (ma >= p || mb >= p) return NTT_OK;  // unreduced input: the 64-bit loads reduce it
+    CopyPool& pool = CopyPool::get();
+    std::vector<uint32_t> part_max((size_t)pool.max_parts() * 2, 0u);
+    pool.for_range(n_in, (size_t)64 << 10, [&](int i, size_t lo, size_t hi) {
+        part_max[2 * i] = narrow_u64(a + lo, pa + lo, hi - lo);
+        part_max[2 * i + 1] = narrow_u64(b + lo, pb + lo, hi - lo);
+    });
+    uint32_t mx = 0;
+    for (uint32_t v : part_max) mx = v > mx ? v : mx;
+    if (mx >= p) return NTT_OK;  // unreduced input: the 64-bit loads reduce it
     if ((rc = dev->io_a.ensure(in_bytes)) != NTT_OK) return rc;
     if ((rc = dev->io_b.ensure(in_bytes)) != NTT_OK) return rc;
     if ((rc = dev->io_out.ensure(out_bytes)) != NTT_OK) return rc;
@@ -882,7 +902,9 @@ int run_host_shard_narrow(Device* dev, const uint64_t* a, const uint64_t* b, uin
                                             nullptr, 0, dev->stream);
     if (rc != NTT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(po, dev->io_out.ptr, out_bytes, hipMemcpyDeviceToHost, dev->stream));
-    finish.push_back([=] { widen_u32(po, ab, n_out); });
+    finish.push_back([=] {
+        CopyPool::get().for_range(n_out, (size_t)64 << 10, [=](int, size_t lo, size_t hi) { widen_u32(po + lo, ab + lo, hi - lo); });
+    });
     *narrowed = true;
     return NTT_OK;
 }
