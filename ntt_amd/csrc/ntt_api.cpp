@@ -11,9 +11,9 @@
 // launch bracketed by profiling events when ntt_profile_enable(1) is in effect
 #define NTT_LAUNCH_P(label, kernel, grid, block, stream, ...)      \
     do {                                                           \
-        prof_begin(label, stream);                                 \
+        const int prof_slot_ = prof_begin(label, stream);          \
         NTT_LAUNCH(kernel, grid, block, stream, __VA_ARGS__);      \
-        prof_end(stream);                                          \
+        prof_end(prof_slot_, stream);                              \
     } while (0)
 
 #include <stdio.h>
@@ -111,7 +111,16 @@ struct Device {
     hipStream_t stream = nullptr;
     std::map<std::pair<uint32_t, int>, std::unique_ptr<Plan>> plans;
     std::map<std::pair<uint64_t, int>, std::unique_ptr<struct Plan64>> plans64;
-    DevBuf work;     // library-owned workspace
+    // library-owned workspaces, one per stream the NULL-workspace calls were enqueued on: calls on different streams may
+    // overlap on the device, so they must not share scratch memory.  A buffer only ever grows; growing frees the old
+    // one with hipFree, which waits for the device first, so nothing in flight loses its memory.
+    std::map<hipStream_t, DevBuf> work;
+    int workspace_for(hipStream_t st, size_t need, void** ws) {
+        DevBuf& b = work[st];
+        int rc = b.ensure(need);
+        if (rc == NTT_OK) *ws = b.ptr;
+        return rc;
+    }
     DevBuf io_a, io_b, io_out;  // device side of the host-pointer entry points
     PinBuf pin;                 // page-locked staging for the same
     // two independent staging sets for host-pointer calls too large for `pin`: chunks alternate between them so that
@@ -164,21 +173,40 @@ int current_device(Device** out) {
 }
 
 // ---- optional per-kernel timing with HIP events on the launch stream ----
-struct ProfRec { const char* label; hipEvent_t e0, e1; };
+// Events come from a pool that is created once and reused by every profiling session, so that a launch inside a
+// session costs two hipEventRecord calls and nothing else.  prof_begin returns the record's slot (-1: not recorded)
+// and prof_end closes exactly that slot.
+struct ProfRec { const char* label; hipEvent_t e0, e1; bool closed; };
 bool g_prof_on = false;
-std::vector<ProfRec> g_prof;
+std::vector<ProfRec> g_prof;       // records of the current session
+std::vector<hipEvent_t> g_prof_pool;  // every event ever created; g_prof_used of them belong to g_prof
+size_t g_prof_used = 0;
+constexpr size_t PROF_MAX_RECORDS = 1 << 16;  // a session stops recording beyond this many launches
 
-void prof_begin(const char* label, hipStream_t st) {
-    if (!g_prof_on) return;
-    ProfRec r; r.label = label; r.e0 = nullptr; r.e1 = nullptr;
-    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
-    if (hipEventRecord(r.e0, st) != hipSuccess) return;
-    g_prof.push_back(r);
+bool prof_event(hipEvent_t* e) {
+    if (g_prof_used < g_prof_pool.size()) { *e = g_prof_pool[g_prof_used++]; return true; }
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) return false;
+    g_prof_pool.push_back(ev);
+    ++g_prof_used;
+    *e = ev;
+    return true;
 }
-void prof_end(hipStream_t st) {
-    if (!g_prof_on || g_prof.empty()) return;
-    hipError_t e = hipEventRecord(g_prof.back().e1, st);
-    (void)e;
+
+int prof_begin(const char* label, hipStream_t st) {
+    if (!g_prof_on || g_prof.size() >= PROF_MAX_RECORDS) return -1;
+    const size_t used_before = g_prof_used;
+    ProfRec r; r.label = label; r.e0 = nullptr; r.e1 = nullptr; r.closed = false;
+    if (!prof_event(&r.e0) || !prof_event(&r.e1) || hipEventRecord(r.e0, st) != hipSuccess) {
+        g_prof_used = used_before;  // the events go back to the pool
+        return -1;
+    }
+    g_prof.push_back(r);
+    return (int)g_prof.size() - 1;
+}
+void prof_end(int slot, hipStream_t st) {
+    if (slot < 0 || (size_t)slot >= g_prof.size()) return;
+    g_prof[slot].closed = hipEventRecord(g_prof[slot].e1, st) == hipSuccess;
 }
 
 // upload helper: appends a vector to a staging image, returns its offset (16-byte aligned)
@@ -287,14 +315,16 @@ int product_device(Device* dev, const TIn* a, const TIn* b, TOut* out, int n, ui
         if (ws) {
             if (ws_bytes < need) return fail(NTT_ERR_WORKSPACE, "workspace too small");
         } else {
-            rc = dev->work.ensure(need);
-            if (rc != NTT_OK) return rc;
-            ws = dev->work.ptr;
+            if ((rc = dev->workspace_for(st, need, &ws)) != NTT_OK) return rc;
         }
     }
     if (pl->h.lazy) return launch_product<true>(*pl, a, b, out, n, batch, sa, sb, so, ws, st);
     return launch_product<false>(*pl, a, b, out, n, batch, sa, sb, so, ws, st);
 }
+
+// grid.y of the per-coefficient kernels: the rows of a batch, capped at the launch limit of that dimension (the kernels
+// stride over the rows beyond it)
+unsigned grid_rows(size_t batch) { return (unsigned)(batch < 65535 ? batch : 65535); }
 
 int make_crt_consts(uint64_t p, CrtConsts* c) {
     if (p < 2) return fail(NTT_ERR_ARG, "modulus must be at least 2");
@@ -314,7 +344,20 @@ int make_crt_consts(uint64_t p, CrtConsts* c) {
     return NTT_OK;
 }
 
-bool direct_path_ok(uint64_t p, int logL) { return p < (1ull << 31) && modulus_is_ntt_friendly(p, logL); }
+// The admission tests cost a primality test and a few modular powers (tens of microseconds): their verdicts are kept
+// per (modulus, length), so that the per-call dispatch of a small product does not repeat them.
+bool direct_path_ok(uint64_t p, int logL) {
+    if (p >= (1ull << 31)) return false;
+    static std::mutex m;
+    static std::map<std::pair<uint64_t, int>, bool> memo;
+    std::lock_guard<std::mutex> lk(m);
+    const auto key = std::make_pair(p, logL);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+    const bool ok = modulus_is_ntt_friendly(p, logL);
+    if (memo.size() < 4096) memo[key] = ok;
+    return ok;
+}
 
 size_t crt_workspace_bytes(int logL, size_t batch) {
     const size_t L = (size_t)1 << logL;
@@ -332,9 +375,8 @@ int crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, uint64
     if (ws) {
         if (ws_bytes < need) return fail(NTT_ERR_WORKSPACE, "workspace too small");
     } else {
-        int rc = dev->work.ensure(need);
+        int rc = dev->workspace_for(st, need, &ws);
         if (rc != NTT_OK) return rc;
-        ws = dev->work.ptr;
     }
     const size_t L = (size_t)1 << logL;
     const size_t pipe = pipeline_workspace_bytes(logL, batch);
@@ -349,7 +391,7 @@ int crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, uint64
     int rc = make_crt_consts(p, &c);
     if (rc != NTT_OK) return rc;
     const size_t count = (size_t)(2 * n - 1);
-    NTT_LAUNCH_P("k_crt_merge", k_crt_merge, dim3((unsigned)((count + 255) / 256), (unsigned)batch), dim3(256), st, (const uint32_t*)res,
+    NTT_LAUNCH_P("k_crt_merge", k_crt_merge, dim3((unsigned)((count + 255) / 256), grid_rows(batch)), dim3(256), st, (const uint32_t*)res,
                res_stride, out, count, batch, so, L, c);
     HIP_TRY(hipGetLastError());
     return NTT_OK;
@@ -359,13 +401,35 @@ int crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, uint64
 // ---------------------------------------------------------------------------------------------
 // 64-bit field path
 // ---------------------------------------------------------------------------------------------
+bool modulus64_test(uint64_t p, int log_root, std::string* why);
 bool modulus64_ok(uint64_t p, int log_root, std::string* why) {
+    static std::mutex m;
+    static std::map<std::pair<uint64_t, int>, std::pair<bool, std::string>> memo;
+    std::lock_guard<std::mutex> lk(m);
+    const auto key = std::make_pair(p, log_root);
+    auto it = memo.find(key);
+    if (it == memo.end()) {
+        std::string w;
+        const bool ok = modulus64_test(p, log_root, &w);
+        if (memo.size() >= 4096) { *why = w; return ok; }
+        it = memo.emplace(key, std::make_pair(ok, w)).first;
+    }
+    *why = it->second.second;
+    return it->second.first;
+}
+bool modulus64_test(uint64_t p, int log_root, std::string* why) {
     if (p >= (1ull << 60) || p < 3 || (p & 1) == 0) { *why = "64-bit path needs an odd modulus below 2^60"; return false; }
     if (log_root < 1 || log_root > 40) { *why = "root order out of range"; return false; }
     const uint64_t L = 1ull << log_root;
     if ((p - 1) % L != 0) { *why = "transform length does not divide p-1"; return false; }
+    if (!is_prime_u64(p)) { *why = "modulus is not prime"; return false; }
     const uint64_t w = h_powmod(3, (p - 1) / L, p);
-    if (h_powmod(w, L / 2, p) != p - 1) { *why = "3 is not a generator of the required 2-power subgroup mod p (p not prime?)"; return false; }
+    if (h_powmod(w, L / 2, p) != p - 1) { *why = "3 is not a generator of the required 2-power subgroup mod p"; return false; }
+    // the inverses the route uses (all Fermat inverses) must really invert
+    if (h_mulmod(h_powmod(L % p, p - 2, p), L % p, p) != 1 || h_mulmod(h_powmod(w, p - 2, p), w, p) != 1) {
+        *why = "transform length or root not invertible mod p";
+        return false;
+    }
     return true;
 }
 
@@ -491,8 +555,7 @@ int field64_product_device(Device* dev, const uint64_t* a, const uint64_t* b, ui
     if (ws) {
         if (ws_bytes < need) return fail(NTT_ERR_WORKSPACE, "workspace too small");
     } else {
-        if ((rc = dev->work.ensure(need)) != NTT_OK) return rc;
-        ws = dev->work.ptr;
+        if ((rc = dev->workspace_for(st, need, &ws)) != NTT_OK) return rc;
     }
     uint64_t* wa = (uint64_t*)ws;
     uint64_t* wb = wa + L;
@@ -548,9 +611,8 @@ int wide_crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, u
     if (ws) {
         if (ws_bytes < need) return fail(NTT_ERR_WORKSPACE, "workspace too small");
     } else {
-        int rc = dev->work.ensure(need);
+        int rc = dev->workspace_for(st, need, &ws);
         if (rc != NTT_OK) return rc;
-        ws = dev->work.ptr;
     }
     const size_t field_ws = need - (size_t)k * batch * (2 * n - 1) * sizeof(uint64_t);
     uint64_t* res = (uint64_t*)((char*)ws + field_ws);
@@ -562,7 +624,7 @@ int wide_crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, u
     WideCrtConsts c;
     int rc = make_wide_crt_consts(p, k, &c);
     if (rc != NTT_OK) return rc;
-    NTT_LAUNCH_P("k64_garner", k64_garner, dim3((unsigned)((count + 255) / 256), (unsigned)batch), dim3(256), st, (const uint64_t*)res,
+    NTT_LAUNCH_P("k64_garner", k64_garner, dim3((unsigned)((count + 255) / 256), grid_rows(batch)), dim3(256), st, (const uint64_t*)res,
                  res_stride, out, count, batch, so, count, c);
     HIP_TRY(hipGetLastError());
     return NTT_OK;
@@ -608,7 +670,7 @@ class CopyPool {
         int parts = (int)((bytes + piece - 1) / piece);
         if (parts > (int)workers_.size() + 1) parts = (int)workers_.size() + 1;
         if (parts <= 1) { memcpy(dst, src, bytes); return; }
-        const size_t per = ((bytes / parts) + 63) & ~(size_t)63;
+        const size_t per = (((bytes + parts - 1) / parts) + 63) & ~(size_t)63;  // ceil: parts * per >= bytes, no tail is lost
         run(parts, [=](int i) {
             const size_t lo = (size_t)i * per;
             if (lo >= bytes) return;
@@ -621,7 +683,7 @@ class CopyPool {
         int parts = (int)((count + grain - 1) / grain);
         if (parts > (int)workers_.size() + 1) parts = (int)workers_.size() + 1;
         if (parts <= 1) { fn(0, 0, count); return; }
-        const size_t per = ((count / parts) + 15) & ~(size_t)15;
+        const size_t per = (((count + parts - 1) / parts) + 15) & ~(size_t)15;  // ceil: parts * per >= count
         run(parts, [&](int i) {
             const size_t lo = (size_t)i * per;
             if (lo >= count) return;
@@ -636,6 +698,8 @@ class CopyPool {
         if (omp && atoi(omp) > 0 && (unsigned)atoi(omp) < hw) hw = (unsigned)atoi(omp);
         int n = hw > 2 ? (int)hw / 2 - 1 : 0;
         if (n > 7) n = 7;
+        const char* forced = getenv("NTT_COPY_WORKERS");   // test hook: exact number of helper threads (0..15)
+        if (forced && forced[0] >= '0' && forced[0] <= '9') n = atoi(forced) > 15 ? 15 : atoi(forced);
         for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
         for (auto& t : workers_) t.detach();
     }
@@ -929,7 +993,9 @@ void ntt_shutdown(void) {
         dev->plans.clear();
         for (auto& kv : dev->plans64) kv.second->tables.release();
         dev->plans64.clear();
-        dev->work.release(); dev->io_a.release(); dev->io_b.release(); dev->io_out.release(); dev->pin.release();
+        for (auto& kv : dev->work) kv.second.release();
+        dev->work.clear();
+        dev->io_a.release(); dev->io_b.release(); dev->io_out.release(); dev->pin.release();
         for (auto& s : dev->stage) {
             s.pin.release(); s.a.release(); s.b.release(); s.out.release(); s.ws.release();
             if (s.stream) { e = hipStreamDestroy(s.stream); (void)e; s.stream = nullptr; }
@@ -939,6 +1005,9 @@ void ntt_shutdown(void) {
     }
     g_devs.clear();
     g_inited = false;
+    g_prof.clear(); g_prof_used = 0; g_prof_on = false;
+    for (hipEvent_t ev : g_prof_pool) { hipError_t e = hipEventDestroy(ev); (void)e; }
+    g_prof_pool.clear();
 }
 
 int ntt_device_count(void) { return g_inited ? g_visible : 0; }
@@ -1252,8 +1321,8 @@ int ntt_transform_u64(uint64_t* a, int n, int invert, uint64_t p) {
 }
 
 int ntt_profile_enable(int on) {
-    for (auto& r : g_prof) { hipError_t e = hipEventDestroy(r.e0); e = hipEventDestroy(r.e1); (void)e; }
     g_prof.clear();
+    g_prof_used = 0;   // the pool's events are reused by the next session
     g_prof_on = on != 0;
     return NTT_OK;
 }
@@ -1263,7 +1332,7 @@ int ntt_profile_read(char* names, size_t names_len, double* total_ms, int* launc
     std::vector<std::string> labels;
     std::string joined;
     for (auto& r : g_prof) {
-        if (!r.e1) continue;
+        if (!r.closed) continue;
         HIP_TRY(hipEventSynchronize(r.e1));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, r.e0, r.e1));

@@ -19,7 +19,7 @@
 
 #include <type_traits>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define NTT_HD __host__ __device__ __forceinline__
 #else
 #define NTT_HD inline

@@ -487,30 +487,31 @@ __device__ __forceinline__ uint64_t rem_2by1(uint64_t u1, uint64_t u0, uint64_t 
 __global__ void __launch_bounds__(256) k_crt_merge(const uint32_t* res, size_t res_stride, uint64_t* out, size_t count,
                                                    size_t rows, size_t out_stride, size_t row_stride, CrtConsts c) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t row = blockIdx.y;
-    if (i >= count || row >= rows) return;
-    uint64_t s_lo = 0, s_hi = 0;
+    if (i >= count) return;
+    for (size_t row = blockIdx.y; row < rows; row += gridDim.y) {   // grid.y is capped at the launch limit
+        uint64_t s_lo = 0, s_hi = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t r = res[(size_t)k * res_stride + row * row_stride + i];
-        const uint32_t t = csub(redc_lazy((uint64_t)r * c.minv_m[k], c.q[k], c.nq[k]), c.q[k]);
-        const uint64_t lo = c.mi_lo[k] * t;
-        const uint64_t hi = __umul64hi(c.mi_lo[k], (uint64_t)t) + (uint64_t)c.mi_hi[k] * t;
-        s_lo += lo;
-        s_hi += hi + (s_lo < lo ? 1u : 0u);
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t r = res[(size_t)k * res_stride + row * row_stride + i];
+            const uint32_t t = csub(redc_lazy((uint64_t)r * c.minv_m[k], c.q[k], c.nq[k]), c.q[k]);
+            const uint64_t lo = c.mi_lo[k] * t;
+            const uint64_t hi = __umul64hi(c.mi_lo[k], (uint64_t)t) + (uint64_t)c.mi_hi[k] * t;
+            s_lo += lo;
+            s_hi += hi + (s_lo < lo ? 1u : 0u);
+        }
+        // S < 4M: subtract 2M, then M, when possible
+        const uint64_t m2_lo = c.M_lo << 1, m2_hi = (c.M_hi << 1) | (c.M_lo >> 63);
+        if (s_hi > m2_hi || (s_hi == m2_hi && s_lo >= m2_lo)) {
+            const uint64_t b = s_lo < m2_lo ? 1u : 0u;
+            s_lo -= m2_lo; s_hi -= m2_hi + b;
+        }
+        if (s_hi > c.M_hi || (s_hi == c.M_hi && s_lo >= c.M_lo)) {
+            const uint64_t b = s_lo < c.M_lo ? 1u : 0u;
+            s_lo -= c.M_lo; s_hi -= c.M_hi + b;
+        }
+        const uint64_t r1 = rem_2by1(0, s_hi, c.d, c.v, c.shift);
+        out[row * out_stride + i] = rem_2by1(r1, s_lo, c.d, c.v, c.shift);
     }
-    // S < 4M: subtract 2M, then M, when possible
-    const uint64_t m2_lo = c.M_lo << 1, m2_hi = (c.M_hi << 1) | (c.M_lo >> 63);
-    if (s_hi > m2_hi || (s_hi == m2_hi && s_lo >= m2_lo)) {
-        const uint64_t b = s_lo < m2_lo ? 1u : 0u;
-        s_lo -= m2_lo; s_hi -= m2_hi + b;
-    }
-    if (s_hi > c.M_hi || (s_hi == c.M_hi && s_lo >= c.M_lo)) {
-        const uint64_t b = s_lo < c.M_lo ? 1u : 0u;
-        s_lo -= c.M_lo; s_hi -= c.M_hi + b;
-    }
-    const uint64_t r1 = rem_2by1(0, s_hi, c.d, c.v, c.shift);
-    out[row * out_stride + i] = rem_2by1(r1, s_lo, c.d, c.v, c.shift);
 }
 
 }  // namespace nttamd

@@ -229,8 +229,7 @@ __device__ __forceinline__ uint64_t rem128(uint64_t u1, uint64_t u0, uint64_t d,
 __global__ void __launch_bounds__(256) k64_garner(const uint64_t* res, size_t res_stride, uint64_t* out, size_t count,
                                                   size_t rows, size_t out_stride, size_t row_stride, WideCrtConsts c) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t row = blockIdx.y;
-    if (i >= count || row >= rows) return;
+    if (i >= count) return;
     auto mont = [](uint64_t x, uint64_t wm, uint64_t q, uint64_t nq) -> uint64_t {  // x*w mod q, canonical
         const uint64_t lo = x * wm, hi = mulhi64(x, wm);
         const uint64_t m = lo * nq;
@@ -238,21 +237,23 @@ __global__ void __launch_bounds__(256) k64_garner(const uint64_t* res, size_t re
         return r >= q ? r - q : r;
     };
     auto csub = [](uint64_t x, uint64_t q) -> uint64_t { return x >= q ? x - q : x; };
-    const uint64_t r1 = res[row * row_stride + i], r2 = res[res_stride + row * row_stride + i];
-    const uint64_t t1 = r1;
-    const uint64_t t2 = mont(r2 - csub(t1, c.q[1]) + c.q[1], c.inv1_m2, c.q[1], c.nq[1]);
-    uint64_t t3 = 0;
-    if (c.k == 3) {
-        const uint64_t r3 = res[2 * res_stride + row * row_stride + i];
-        const uint64_t u = mont(r3 - csub(t1, c.q[2]) + c.q[2], c.inv1_m3, c.q[2], c.nq[2]);
-        t3 = mont(u - csub(t2, c.q[2]) + c.q[2], c.inv2_m3, c.q[2], c.nq[2]);
-    }
     auto modp = [&](uint64_t x) -> uint64_t { return rem128(0, x, c.d, c.v, c.shift); };
     auto mulp = [&](uint64_t a, uint64_t b) -> uint64_t { return rem128(mulhi64(a, b), a * b, c.d, c.v, c.shift); };  // a, b < p
     auto addp = [&](uint64_t a, uint64_t b) -> uint64_t { const uint64_t s = a + b; return (s < a || s >= c.p) ? s - c.p : s; };
-    uint64_t acc = addp(modp(t1), mulp(c.q1_p, modp(t2)));
-    if (c.k == 3) acc = addp(acc, mulp(c.q12_p, modp(t3)));
-    out[row * out_stride + i] = acc;
+    for (size_t row = blockIdx.y; row < rows; row += gridDim.y) {   // grid.y is capped at the launch limit
+        const uint64_t r1 = res[row * row_stride + i], r2 = res[res_stride + row * row_stride + i];
+        const uint64_t t1 = r1;
+        const uint64_t t2 = mont(r2 - csub(t1, c.q[1]) + c.q[1], c.inv1_m2, c.q[1], c.nq[1]);
+        uint64_t t3 = 0;
+        if (c.k == 3) {
+            const uint64_t r3 = res[2 * res_stride + row * row_stride + i];
+            const uint64_t u = mont(r3 - csub(t1, c.q[2]) + c.q[2], c.inv1_m3, c.q[2], c.nq[2]);
+            t3 = mont(u - csub(t2, c.q[2]) + c.q[2], c.inv2_m3, c.q[2], c.nq[2]);
+        }
+        uint64_t acc = addp(modp(t1), mulp(c.q1_p, modp(t2)));
+        if (c.k == 3) acc = addp(acc, mulp(c.q12_p, modp(t3)));
+        out[row * out_stride + i] = acc;
+    }
 }
 
 }  // namespace nttamd

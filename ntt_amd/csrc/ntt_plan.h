@@ -37,6 +37,33 @@ inline uint32_t h_neg_inv32(uint32_t p) {  // -p^-1 mod 2^32, p odd
 }
 inline uint32_t h_mont(uint64_t x, uint32_t p) { return (uint32_t)(((u128)(x % p) << 32) % p); }
 
+// Deterministic Miller-Rabin for 64-bit integers (the first twelve prime bases decide every n < 3.3 * 10^24).
+// Every inverse on the transform paths is a Fermat inverse x^(p-2), which is only an inverse when p is prime, and a
+// pseudoprime can pass the generator test 3^((p-1)/2) = -1: moduli are admitted to the direct transform routes only
+// when this says prime (composite moduli are still served, by the CRT routes).
+inline bool is_prime_u64(uint64_t n) {
+    if (n < 2) return false;
+    static const uint64_t small[12] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    for (uint64_t q : small) {
+        if (n == q) return true;
+        if (n % q == 0) return false;
+    }
+    uint64_t d = n - 1;
+    int r = 0;
+    while ((d & 1) == 0) { d >>= 1; ++r; }
+    for (uint64_t a : small) {
+        uint64_t x = h_powmod(a, d, n);
+        if (x == 1 || x == n - 1) continue;
+        bool composite = true;
+        for (int i = 1; i < r; ++i) {
+            x = h_mulmod(x, x, n);
+            if (x == n - 1) { composite = false; break; }
+        }
+        if (composite) return false;
+    }
+    return true;
+}
+
 inline int ceil_log2(uint64_t x) {
     int l = 0;
     while ((1ull << l) < x) ++l;
@@ -56,6 +83,7 @@ inline bool modulus_is_ntt_friendly(uint64_t p, int logL, std::string* why = nul
     if (p >= (1ull << 31) || p < 3 || (p & 1) == 0) { if (why) *why = "modulus must be odd and below 2^31 for the direct path"; return false; }
     const uint64_t L = 1ull << logL;
     if ((p - 1) % L != 0) { if (why) *why = "transform length does not divide p-1"; return false; }
+    if (!is_prime_u64(p)) { if (why) *why = "modulus is not prime"; return false; }
     const uint64_t w = h_powmod(3, (p - 1) / L, p);
     if (h_powmod(w, L / 2, p) != p - 1) { if (why) *why = "3 is not a generator of the required 2-power subgroup mod p (p not prime?)"; return false; }
     const uint64_t linv = h_powmod(L % p, p - 2, p);

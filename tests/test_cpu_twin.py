@@ -122,6 +122,17 @@ def test_64bit_field_rejects_unfriendly_moduli(twin):
         _twin_mul64(twin, a, a, 1000000007)      # 16 does not divide p-1
     with pytest.raises(NttError):
         _twin_mul64(twin, a, a, 2**61 - 1)       # above the 2^60 limit
+    # composite moduli with 16 | p-1 never reach the field kernels (their Fermat inverses would not invert): 1729 is a
+    # Carmichael number, 4097 = 17 * 241, 2^32 + 1 = 641 * 6700417
+    for composite in (1729, 4097, 2**32 + 1):
+        with pytest.raises(NttError, match="not prime"):
+            _twin_mul64(twin, a, a, composite)
+    # ... while the general entry point still serves them, through a CRT route
+    rng = np.random.default_rng(1729)
+    from oracle_binding import Oracle
+    for composite in (1729, 2**32 + 1):
+        x = rng.integers(0, composite, 8, dtype=np.uint64); y = rng.integers(0, composite, 8, dtype=np.uint64)
+        assert np.array_equal(twin.multiply_u64(x, y, composite), Oracle().schoolbook_u64(x, y, composite))
 
 
 def test_explicit_fourstep_matrix_form(twin, oracle):
@@ -328,3 +339,39 @@ def run_pipelined_worker(lib_path, tmp_path):
 def test_large_host_calls_go_through_in_chunks(twin, tmp_path):
     """Host-pointer calls beyond the staging limit (lowered here by the test hook) alternate between two staging sets."""
     run_pipelined_worker(twin.path, tmp_path)
+
+
+TAIL_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from ntt_amd._binding import NttLibrary
+from oracle_binding import Oracle
+lib = NttLibrary(LIB); orc = Oracle()
+rng = np.random.default_rng(11)
+p, n = 998244353, 4096
+ok = True
+for batch in (31, 127, 257):
+    a = rng.integers(0, p, (batch, n), dtype=np.uint32); b = rng.integers(0, p, (batch, n), dtype=np.uint32)
+    got = lib.multiply_batched(a, b, p, 1)
+    got64 = lib.multiply_batched_u64(a.astype(np.uint64), b.astype(np.uint64), p, 1)   # narrowed on the way in, widened on the way out
+    for r in (0, batch - 2, batch - 1):
+        want = orc.ntt_multiply(a[r], b[r], p)
+        ok = ok and np.array_equal(got[r].astype(np.uint64), want) and np.array_equal(got64[r], want)
+print("RESULT", ok)
+'''
+
+
+@pytest.mark.parametrize("workers,limit_mb", [(0, 64), (1, 64), (3, 64), (6, 64), (7, 64), (7, 1), (2, 2)])
+def test_staged_copies_keep_the_tail_of_odd_sized_batches(twin, tmp_path, workers, limit_mb):
+    """Row counts whose byte total is not a multiple of (copy threads x 64 B): the last coefficients of the last row must arrive
+    (inputs) and come back (outputs) whatever the number of copy threads and the staging limit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "tail.py"
+    script.write_text(f"ROOT = {root!r}\nLIB = {twin.path!r}\n" + TAIL_WORKER)
+    env = dict(os.environ, NTT_COPY_WORKERS=str(workers), NTT_STAGE_LIMIT_MB=str(limit_mb))
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RESULT True" in r.stdout, r.stdout[-500:]
