@@ -65,18 +65,111 @@ def cpu_baseline(n, p, min_seconds=12.0, max_reps=100000):
 
 
 def load_traffic(kernel, batch):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/traffic_*.json), which was
-    collected at the batch size recorded in it (256 when absent); traffic is proportional to the batch."""
+    """(HBM bytes per launch of `kernel`, source) from the newest committed PMC summary (profiles/traffic_*.json), which
+    was collected at the batch size recorded in it (256 when absent); traffic is proportional to the batch.  The figure
+    is static: it describes the kernels as they were when that profile was taken, not this run."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")))
     if not files:
-        return None
+        return None, None
     try:
         with open(files[-1]) as f:
             d = json.load(f)
         per_launch = d.get(kernel, {}).get("hbm_bytes_per_launch")
-        return None if per_launch is None else per_launch * batch / d.get("_meta", {}).get("batch", 256)
+        if per_launch is None:
+            return None, None
+        return per_launch * batch / d.get("_meta", {}).get("batch", 256), f"profiles/{os.path.basename(files[-1])} (static, rocprofv3 --pmc)"
+    except Exception:
+        return None, None
+
+
+def valu_roofline(kernel, batch, avg_ms):
+    """Integer-issue roofline of one kernel: vector instructions per launch (SQ_INSTS_VALU of the newest committed
+    profiles/*_pmc.json, scaled to the batch) against the rate at which the chip can issue that instruction mix
+    (profiles/valu_issue.json: cycles per wave-instruction per SIMD measured by tools/ubench_valu.hip for plain and
+    multiply-class instructions, and the kernel's share of multiply-class instructions from its disassembly)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_issue.json")) as f:
+            iss = json.load(f)
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+        with open(pmcs[-1]) as f:
+            pmc = json.load(f)
+        insts = pmc[kernel]["SQ_INSTS_VALU"] * batch / iss.get("pmc_batch", 256)
+        mix = iss["kernels"][kernel]["multiply_class_fraction"]
+        cyc = mix * iss["cycles_per_wave_inst"]["multiply_class"] + (1 - mix) * iss["cycles_per_wave_inst"]["plain"]
+        peak = iss["simds"] * iss["clock_GHz"] * 1e9 / cyc
+        achieved = insts / (avg_ms * 1e-3)
+        return {"kernel": kernel, "wave_insts_per_launch": insts, "multiply_class_fraction": mix,
+                "issue_cycles_per_wave_inst": cyc, "peak_wave_insts_per_s": peak, "achieved_wave_insts_per_s": achieved,
+                "frac": achieved / peak,
+                "source": f"profiles/{os.path.basename(pmcs[-1])} + profiles/valu_issue.json (static)"}
     except Exception:
         return None
+
+
+def free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` started as one plain process: fan out to N rank processes (one per GPU), the way the
+    reference's MPI programs are started with `mpiexec -np N` (qsub_mpi.sh:16), and relay rank 0's line.  This parent
+    never touches torch or the GPU; the ranks are fresh children that find RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    their environment, exactly as under torch.distributed.run."""
+    import subprocess
+    port = str(free_port())
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    for l in out0.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if any(codes) or not lines:
+        raise SystemExit(f"bench.py: the {args.gpus}-rank run failed (exit codes {codes})")
+    line = json.loads(lines[-1])
+    if line.get("n_gpus") != args.gpus:
+        raise SystemExit(f"bench.py: asked for {args.gpus} GPUs but the ranks report n_gpus={line.get('n_gpus')}")
+    print(lines[-1], flush=True)
+
+
+def verify_products(torch, a, b, out, n, p, rows, oracle_rows):
+    """Every product of the batch is checked on the device through the evaluation identity A(x) * B(x) = C(x) (mod p) at
+    two seeded random points (a wrong coefficient survives one point with probability < 2n/p), and `oracle_rows` of them
+    are compared bit for bit with the CPU oracle.  Runs after the timed region; test infrastructure, not product code."""
+    import numpy as np
+    from oracle_binding import Oracle
+    dev = a.device
+    g = torch.Generator(device="cpu"); g.manual_seed(0xC0DE)
+    ok_eval = True
+    for _ in range(2):
+        x = int(torch.randint(2, p - 1, (1,), generator=g).item())
+        pw = torch.ones(1, dtype=torch.int64, device=dev)
+        step = x
+        while pw.numel() < 2 * n:       # powers x^0 .. x^(2n-1) by doubling
+            pw = torch.cat([pw, pw * step % p])
+            step = step * step % p
+        def ev(t, count):
+            acc = torch.zeros(t.shape[0], dtype=torch.int64, device=dev)
+            for lo in range(0, t.shape[0], 32):     # 32 rows at a time keeps the 64-bit temporaries small
+                v = t[lo:lo + 32, :count].to(torch.int64) & 0xFFFFFFFF
+                acc[lo:lo + 32] = (v * pw[:count] % p).sum(dim=1) % p
+            return acc
+        lhs = ev(a[:rows], n) * ev(b[:rows], n) % p
+        ok_eval = ok_eval and bool(torch.equal(lhs, ev(out[:rows], 2 * n - 1)))
+    orc = Oracle()
+    pick = sorted(set([0, 1, rows - 1] + list(range(0, rows, max(1, rows // max(1, oracle_rows))))))[:max(3, oracle_rows)]
+    pick = [r for r in pick if r < rows]
+    ah = a[pick].cpu().numpy().view(np.uint32); bh = b[pick].cpu().numpy().view(np.uint32); oh = out[pick].cpu().numpy().view(np.uint32)
+    ok_exact = all(np.array_equal(oh[i, :2 * n - 1].astype(np.uint64), orc.ntt_multiply(ah[i], bh[i], p)) for i in range(len(pick)))
+    return {"all_products_evaluation_identity": ok_eval, "rows_checked": rows, "oracle_rows_bit_exact": len(pick),
+            "oracle_ok": ok_exact, "ok": bool(ok_eval and ok_exact)}
 
 
 def main():
@@ -87,7 +180,8 @@ def main():
     ap.add_argument("--ramp-ms", type=float, default=150.0,
                     help="untimed run of the same workload before the warm-up steps, long enough for the GPU's clock "
                          "management to settle (it dips for the first ~25 ms of a sustained load); 0 disables")
-    ap.add_argument("--n", type=int, default=131072)
+    ap.add_argument("--n", "--size", dest="n", type=int, default=131072,
+                    help="coefficients per operand (--size is the spelling to use under torch.distributed.run, whose own parser claims --n)")
     ap.add_argument("--p", type=int, default=998244353)
     ap.add_argument("--batch", type=int, default=256, help="products per GPU per step")
     ap.add_argument("--input-sets", type=int, default=4,
@@ -96,8 +190,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--lib", default=None, help="diagnostic: load this build of the library instead of the shipped one")
-    ap.add_argument("--no-verify", action="store_true", help="diagnostic: skip the oracle spot-check (ablated builds)")
+    ap.add_argument("--no-verify", action="store_true", help="diagnostic: skip the result checks (ablated builds)")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="rehearsal of the multi-rank control flow without GPUs: CPU tensors, gloo, and the library given by "
+                         "--lib (the test-only CPU twin); the line is marked as a rehearsal and is not a measurement")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, sys.argv[1:])
 
     import numpy as np
     import torch
@@ -107,17 +208,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU")
-    device_index = local_rank % torch.cuda.device_count()  # one rank per GPU; wraps only in single-GPU rehearsals
-    torch.cuda.set_device(device_index)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    cpu = args.rehearse_cpu
+    if cpu and not args.lib:
+        raise SystemExit("--rehearse-cpu needs --lib (the CPU twin); the shipped library has no CPU path")
     backend = None
+    if not cpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU")
+        backend = os.environ.get("NTT_BENCH_BACKEND", "nccl")
+        if world > torch.cuda.device_count() and backend == "nccl":
+            raise SystemExit(f"bench.py: --gpus {world} needs {world} GPUs, this node shows {torch.cuda.device_count()}")
+        device_index = local_rank % torch.cuda.device_count()  # one rank per GPU; wraps only in gloo rehearsals
+        torch.cuda.set_device(device_index)
+        dev = torch.device("cuda", device_index)
+    else:
+        backend, dev = "gloo", torch.device("cpu")
     if world > 1:
         # RCCL carries the barrier and the max-reduce of the clock (the products themselves need no collective);
         # NTT_BENCH_BACKEND=gloo rehearses the multi-rank logic on a box with fewer GPUs than ranks
-        backend = os.environ.get("NTT_BENCH_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
     n, p, B = args.n, args.p, args.batch
@@ -129,16 +241,20 @@ def main():
         lib = load_product_library()
     lib.init(0)
 
-    gen = torch.Generator(device="cuda"); gen.manual_seed(0x5EED0000 + rank)
+    def sync():
+        if not cpu:
+            torch.cuda.synchronize()
+
+    gen = torch.Generator(device=dev); gen.manual_seed(0x5EED0000 + rank)
     sets = max(1, args.input_sets)
-    a_sets = [torch.randint(0, p, (B, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32) for _ in range(sets)]
-    b_sets = [torch.randint(0, p, (B, n), generator=gen, device="cuda", dtype=torch.int64).to(torch.int32) for _ in range(sets)]
+    a_sets = [torch.randint(0, p, (B, n), generator=gen, device=dev, dtype=torch.int64).to(torch.int32) for _ in range(sets)]
+    b_sets = [torch.randint(0, p, (B, n), generator=gen, device=dev, dtype=torch.int64).to(torch.int32) for _ in range(sets)]
     a, b = a_sets[-1], b_sets[-1]   # the set of the last timed step is the one verified below
-    out = torch.zeros((B, L), dtype=torch.int32, device="cuda")
+    out = torch.zeros((B, L), dtype=torch.int32, device=dev)
     turn = [0]
     ws_bytes = lib.lib.ntt_workspace_bytes(n, p, B)
-    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    stream = None if cpu else torch.cuda.current_stream().cuda_stream
 
     def step():
         k = turn[0] % sets
@@ -148,18 +264,19 @@ def main():
         lib.check(st)
 
     def fence():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            sync()
 
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         # the first collectives create the communicator (seconds): do that before the ramp, so that the barrier in
         # front of the timed region is a short one and the GPUs enter it warm
         dist.barrier()
-        tw = torch.zeros(1, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tw = torch.zeros(1, dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        torch.cuda.synchronize()
+        sync()
     # Clock ramp, untimed and declared in the output line: on MI355X the first ~25 ms of a sustained integer load
     # run up to 40 % slower than the steady state that follows (per-launch trace in profiles/), so a short
     # benchmark would time the transient instead of the throughput.
@@ -168,26 +285,40 @@ def main():
         while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
             for _ in range(8):
                 step()
-            torch.cuda.synchronize()
+            sync()
     for _ in range(args.warmup):
         step()
     turn[0] = sets - (args.steps % sets)   # so that the last timed step uses the last set
     fence()
-    if not args.no_kernel_events:
-        lib.lib.ntt_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel durations from the HIP events recorded on the launch stream during the timed steps
+    # Every product of this rank's last step is checked (evaluation identity on the device) and 1/16 of them bit for
+    # bit against the oracle; the verdicts of all ranks are combined.  Outside the timed region.
+    verified = None
+    if not args.no_verify:
+        verified = verify_products(torch, a, b, out, n, p, B, max(1, B // 16))
+        if world > 1:
+            flag = torch.tensor([1.0 if verified["ok"] else 0.0], dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            verified["all_ranks_ok"] = bool(flag.item() == 1.0)
+            verified["ok"] = verified["all_ranks_ok"]
+
+    # Per-kernel durations: a separate, untimed pass of the same steps with every launch bracketed by HIP events on the
+    # launch stream (the headline loop above runs without them).
     kernels = {}
-    if not args.no_kernel_events:
+    if not args.no_kernel_events and rank == 0:
+        lib.lib.ntt_profile_enable(1)
+        for _ in range(min(args.steps, 50)):
+            step()
+        sync()
         names = ctypes.create_string_buffer(512)
         ms = (ctypes.c_double * 16)(); cnt = (ctypes.c_int * 16)()
         lib.lib.ntt_profile_read.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
@@ -197,19 +328,10 @@ def main():
             kernels[lab] = {"avg_ms": ms[i] / max(cnt[i], 1), "launches": cnt[i]}
         lib.lib.ntt_profile_enable(0)
 
-    # spot-check three products of this rank's batch against the oracle (outside the timed region)
-    verified = None
-    if rank == 0 and not args.no_verify:
-        from oracle_binding import Oracle
-        orc = Oracle()
-        res = out.cpu().numpy()
-        ah, bh = a.cpu().numpy(), b.cpu().numpy()
-        verified = all(np.array_equal(res[r, :2 * n - 1].astype(np.uint64), orc.ntt_multiply(ah[r], bh[r], p)) for r in (0, 1, B - 1))
-
     # what a plain device-to-device copy reaches on this GPU (read + write bytes per second), outside the timed
     # region: the practical ceiling to read the 8 TB/s spec peak against
     copy_gbs = None
-    if rank == 0:
+    if rank == 0 and not cpu:
         src = torch.empty(1 << 28, dtype=torch.int32, device="cuda"); dst = torch.empty_like(src)  # 1 GiB each
         dst.copy_(src); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -223,47 +345,58 @@ def main():
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * B / (elapsed / args.steps)
-        # Algorithmic bytes of a product under the two-pass model (every transform makes two passes over
-        # memory, padding never read, pointwise fused, 2n-1 outputs): 96*n.  Share per kernel: column pass of A
-        # and B (read 4n, write 8n each) 24n; fused core (second pass of both forward transforms 32n, pointwise,
-        # first pass of the inverse 24n) 56n; inverse column pass (read 8n, write 8n) 16n.  Because the core
-        # keeps the spectra on chip, only 24n of its 56n (read 16n, write 8n) is HBM traffic in this design:
-        # `moved` prices the kernels on the bytes they must actually move.
+        # Algorithmic bytes of a product under the two-pass model (every transform makes two passes over memory,
+        # padding never read, pointwise fused, 2n-1 outputs): 96*n.  `roofline.achieved` prices the whole path of one
+        # GPU on that model -- products per second x 96n -- which is what the HBM target of the path refers to; the
+        # kernels of this design move 64*n per product (the spectra never leave the chip), `achieved_moved`.
+        # Per kernel: share of the model (column pass of A and B 24n; fused core 56n; inverse column pass 16n) and
+        # bytes it must really move (24n / 24n / 16n).
         alg = {"k_fwd_strided": 24 * n * B, "k_core_mul": 56 * n * B, "k_inv_strided": 16 * n * B,
                "k_fused8192": 16 * n * B, "k_small": 16 * n * B}
         moved = {"k_fwd_strided": 24 * n * B, "k_core_mul": 24 * n * B, "k_inv_strided": 16 * n * B,
                  "k_fused8192": 16 * n * B, "k_small": 16 * n * B}
-        roofline = None
-        if kernels and not all(k_ in alg for k_ in kernels):
-            # a diagnostic build with other kernels: report their times only
-            roofline = {"kernels": {k_: {"avg_ms": v["avg_ms"], "launches": v["launches"]} for k_, v in kernels.items()}}
-        elif kernels:
+        per_gpu = value / world
+        multipass = n > 4096
+        model_bytes = 96 * n if multipass else 16 * n
+        moved_bytes = 64 * n if multipass else 16 * n
+        path_gbs, moved_gbs = per_gpu * model_bytes / 1e9, per_gpu * moved_bytes / 1e9
+        roofline = {"bound": "hbm", "scope": "whole path of one GPU: products/s x algorithmic bytes per product",
+                    "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": path_gbs / HBM_PEAK_GBS,
+                    "bytes_per_product_model": model_bytes, "bytes_per_product_moved": moved_bytes,
+                    "achieved_moved": moved_gbs, "frac_moved": moved_gbs / HBM_PEAK_GBS,
+                    "traffic": None, "traffic_source": None, "measured_copy_GBps": copy_gbs}
+        if kernels and not all(v["avg_ms"] > 0 for v in kernels.values()):
+            roofline["kernels"] = {k_: {"avg_ms": v["avg_ms"], "launches": v["launches"]} for k_, v in kernels.items()}
+        elif kernels and all(k_ in alg for k_ in kernels):
             dom = max(kernels, key=lambda k_: kernels[k_]["avg_ms"])
             dur = kernels[dom]["avg_ms"] * 1e-3
-            achieved = alg[dom] / dur / 1e9
-            path_gbs = value / world * 96 * n / 1e9
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(dom, B),
-                        "bytes_per_launch": alg[dom], "avg_launch_ms": kernels[dom]["avg_ms"],
-                        "bytes_model": "two-pass model, 96*n per product; this kernel's share 56*n (k_core_mul), "
-                                       "24*n (k_fwd_strided), 16*n (k_inv_strided)",
-                        "moved_bytes_per_launch": moved[dom], "achieved_moved": moved[dom] / dur / 1e9,
-                        "frac_moved": moved[dom] / dur / 1e9 / HBM_PEAK_GBS,
-                        "kernels": {k_: {"avg_ms": v["avg_ms"], "launches": v["launches"],
-                                         "GBps_model": alg[k_] / (v["avg_ms"] * 1e-3) / 1e9,
-                                         "GBps_moved": moved[k_] / (v["avg_ms"] * 1e-3) / 1e9} for k_, v in kernels.items()},
-                        "measured_copy_GBps": copy_gbs,
-                        "path": {"bytes_per_product_model": 96 * n,
-                                 "bytes_per_product_moved": sum(moved[k_] for k_ in kernels) // B,
-                                 "achieved": path_gbs, "frac": path_gbs / HBM_PEAK_GBS}}
+            traffic, traffic_src = load_traffic(dom, B)
+            roofline.update({
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_kernel": dom,
+                "dominant_kernel": {"kernel": dom, "avg_launch_ms": kernels[dom]["avg_ms"],
+                                    "bytes_per_launch_model": alg[dom], "GBps_model": alg[dom] / dur / 1e9,
+                                    "frac_model": alg[dom] / dur / 1e9 / HBM_PEAK_GBS,
+                                    "bytes_per_launch_moved": moved[dom], "GBps_moved": moved[dom] / dur / 1e9,
+                                    "frac_moved": moved[dom] / dur / 1e9 / HBM_PEAK_GBS},
+                "kernels": {k_: {"avg_ms": v["avg_ms"], "launches": v["launches"],
+                                 "GBps_model": alg[k_] / (v["avg_ms"] * 1e-3) / 1e9,
+                                 "GBps_moved": moved[k_] / (v["avg_ms"] * 1e-3) / 1e9} for k_, v in kernels.items()},
+                "kernel_times": "HIP events on the launch stream, separate untimed pass after the timed steps",
+                "valu": valu_roofline(dom, B, kernels[dom]["avg_ms"])})
+        elif kernels:   # a diagnostic build with other kernels: report their times only
+            roofline["kernels"] = {k_: {"avg_ms": v["avg_ms"], "launches": v["launches"]} for k_, v in kernels.items()}
         line = {"metric": "poly-mults/sec at n=2^17 batched", "value": value, "unit": "poly-mults/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                 "config": {"workload": f"batched poly_multiply n={n} p={p}, {B} products per GPU per step, "
                                        f"inputs/outputs resident in HBM (the n = 2^17, p = 998244353 configuration, batched)",
                            "n": n, "p": p, "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}"},
-                "ramp_ms_untimed": args.ramp_ms, "input_sets": sets, "verified_vs_oracle": verified, "roofline": roofline}
-        if world == 1 and not args.no_cpu_baseline:
+                "ramp_ms_untimed": args.ramp_ms, "input_sets": sets,
+                "verified_vs_oracle": None if verified is None else verified["ok"], "verification": verified,
+                "roofline": roofline}
+        if cpu:
+            line["rehearsal"] = "CPU twin over gloo: control-flow rehearsal, not a measurement"
+        if world == 1 and not args.no_cpu_baseline and not cpu:
             line["cpu_baseline"] = cpu_baseline(n, p)
         print(json.dumps(line), flush=True)
     if world > 1:

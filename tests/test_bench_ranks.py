@@ -1,0 +1,52 @@
+"""bench.py's multi-rank control flow without GPUs: `--gpus N` started as one plain process fans out to N ranks (the
+place of the reference's `mpiexec -np N`, qsub_mpi.sh:16), the launcher form used for N > 1 agrees with it, and a
+mismatch between `--gpus` and the started ranks is an error, never a mislabelled line.  The ranks run the test-only
+CPU twin over gloo (`--rehearse-cpu`), and the line says so."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TWIN = os.path.join(ROOT, "tests", "cpu_twin", "libnttamd_cputwin.so")
+SMALL = ["--steps", "3", "--warmup", "1", "--ramp-ms", "0", "--size", "2048", "--batch", "4", "--no-cpu-baseline",
+         "--rehearse-cpu", "--lib", TWIN]
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+def json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-1000:]
+    return json.loads(lines[0])
+
+
+def clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+
+
+def test_gpus_flag_alone_starts_that_many_ranks():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True,
+                       timeout=300, env=clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "batch-sharded x2" and "rehearsal" in d
+    assert d["verified_vs_oracle"] is True and d["verification"]["all_ranks_ok"] is True
+    assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6   # whole-job rate over both ranks
+
+
+def test_launcher_form_and_rank_mismatch():
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py")]
+    r = subprocess.run(base + ["--gpus", "2"] + SMALL, capture_output=True, text=True, timeout=300, env=clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json_line(r.stdout)["n_gpus"] == 2
+    # two ranks started, one GPU asked for: refuse
+    base[base.index("--master-port") + 1] = str(free_port())
+    r = subprocess.run(base + ["--gpus", "1"] + SMALL, capture_output=True, text=True, timeout=300, env=clean_env(), cwd=ROOT)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "--gpus 1 but the launcher started 2" in r.stderr

@@ -25,8 +25,29 @@ def test_bench_line_has_the_contract_keys():
     assert d["unit"] == "poly-mults/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert d["verified_vs_oracle"] is True and "workload" in d["config"] and "model" not in d["config"]
     roof = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "frac_moved", "achieved_moved",
+                "dominant_kernel", "kernels", "valu"):
         assert key in roof, key
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert d["value"] > 0 and abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # the headline fraction prices the whole path: products/s x 96n bytes against the peak; 64n is what really moves
+    n = d["config"]["n"]
+    assert abs(roof["achieved"] - d["value"] * 96 * n / 1e9) / roof["achieved"] < 1e-9
+    assert abs(roof["achieved_moved"] - d["value"] * 64 * n / 1e9) / roof["achieved_moved"] < 1e-9
+    assert "static" in roof["traffic_source"] and set(roof["kernels"]) == {"k_fwd_strided", "k_core_mul", "k_inv_strided"}
+    assert roof["valu"] is not None and 0 < roof["valu"]["frac"] < 1.5 and roof["valu"]["kernel"] == roof["dominant_kernel"]["kernel"]
+    ver = d["verification"]
+    assert ver["all_products_evaluation_identity"] is True and ver["rows_checked"] == 8 and ver["oracle_ok"] is True
+
+
+def test_more_gpus_than_the_node_has_is_an_error_not_a_smaller_run():
+    import torch
+    want = torch.cuda.device_count() + 1
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "2", "--warmup", "1", "--ramp-ms", "0",
+           "--batch", "2", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert f"--gpus {want} needs {want} GPUs" in r.stderr
