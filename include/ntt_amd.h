@@ -87,6 +87,20 @@ int ntt_poly_multiply_batched_device_u64(const uint64_t *d_a, const uint64_t *d_
                                          size_t batch, size_t a_stride, size_t b_stride, size_t ab_stride,
                                          void *workspace, size_t workspace_bytes, void *stream);
 
+/* The products of ntt_poly_multiply_batched_device for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference, whose multiply
+ * allocates its temporaries on every call (new[]/delete[], main_naive.cc:143-144,175-176).  The call allocates nothing,
+ * on the device or through the runtime: the intermediates of the multi-pass path live in a static device array of
+ * 32 MiB that every GPU the library runs on holds until the process ends, and the twiddle tables must already be cached --
+ * call ntt_init() and run one product with the same n and p through ntt_poly_multiply_batched_device on this device
+ * first.  Limits: batch * 2 * L * 4 bytes <= 32 MiB for transform lengths L > 8192 (16 products at n = 2^17, 128 at
+ * n = 2^14); shorter products need no scratch and any batch is accepted.  Larger calls fail with NTT_ERR_WORKSPACE,
+ * unprepared ones with NTT_ERR_ARG / NTT_ERR_DEVICE.  All calls on one GPU share that GPU's array: calls that overlap on
+ * one GPU (two streams) race; calls on one stream are ordered and safe.  Nothing in the array needs clearing between
+ * calls (every word used is written before it is read). */
+int ntt_poly_multiply_batched_device_noalloc(const uint32_t *d_a, const uint32_t *d_b, uint32_t *d_ab, int n, uint32_t p,
+                                             size_t batch, size_t a_stride, size_t b_stride, size_t ab_stride, void *stream);
+
 /* The CRT recombination on its own (the merge loop of main_naive.cc:216-223 / the slice merge of
  * main_mpi_CRT.cc:512-522): d_res holds the four residue vectors (moduli 1004535809, 1224736769,
  * 469762049, 998244353 in this order), res_stride elements apart, count values each; writes

@@ -23,6 +23,7 @@ EXPORTS = [
     "poly_multiply", "poly_multiply_u64", "ntt_poly_multiply_i32", "ntt_poly_multiply_u64",
     "ntt_poly_multiply_batched", "ntt_poly_multiply_batched_u64",
     "ntt_workspace_bytes", "ntt_poly_multiply_batched_device", "ntt_poly_multiply_batched_device_u64",
+    "ntt_poly_multiply_batched_device_noalloc",
     "ntt_crt_merge_device", "ntt_crt_residue_product_device", "ntt_crt_prime", "ntt_describe_plan",
     "ntt64_transform_device", "ntt64_twiddle_device", "ntt64_pointwise_device", "ntt64_load_device",
     "ntt64_finalize_device", "ntt64_workspace_bytes", "ntt64_poly_multiply_device",
@@ -65,6 +66,8 @@ class NttLibrary:
         dev_args = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.ntt_poly_multiply_batched_device.argtypes = dev_args + [ctypes.c_uint32] + [ctypes.c_size_t] * 4 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.ntt_poly_multiply_batched_device.restype = ctypes.c_int
+        L.ntt_poly_multiply_batched_device_noalloc.argtypes = dev_args + [ctypes.c_uint32] + [ctypes.c_size_t] * 4 + [ctypes.c_void_p]
+        L.ntt_poly_multiply_batched_device_noalloc.restype = ctypes.c_int
         L.ntt_poly_multiply_batched_device_u64.argtypes = dev_args + [ctypes.c_uint64] + [ctypes.c_size_t] * 4 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.ntt_poly_multiply_batched_device_u64.restype = ctypes.c_int
         L.ntt_crt_merge_device.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_void_p]

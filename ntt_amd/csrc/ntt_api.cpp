@@ -91,6 +91,13 @@ struct PinBuf {
     }
 };
 
+// Scratch of the entry point that allocates nothing (ntt_poly_multiply_batched_device_noalloc): the two intermediate
+// arrays of the multi-pass path live in this file-scope device array instead of a hipMalloc'ed workspace.  Every GPU the
+// library runs on holds its own copy at its own address for the life of the process; host code never uses the array's
+// name as an address -- the per-device address is looked up once (Device::scratch, set in get_device).
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)32 << 20;
+static __device__ __align__(256) unsigned char g_noalloc_scratch[NOALLOC_SCRATCH_BYTES];
+
 struct Plan {
     PlanHost h;  // host image without the big vectors after upload (kept: small)
     DevBuf tables;
@@ -109,6 +116,7 @@ struct Plan64 {
 struct Device {
     int id = 0;
     hipStream_t stream = nullptr;
+    void* scratch = nullptr;   // this device's address of g_noalloc_scratch
     std::map<std::pair<uint32_t, int>, std::unique_ptr<Plan>> plans;
     std::map<std::pair<uint64_t, int>, std::unique_ptr<struct Plan64>> plans64;
     // library-owned workspaces, one per stream the NULL-workspace calls were enqueued on: calls on different streams may
@@ -137,6 +145,9 @@ std::map<int, std::unique_ptr<Device>> g_devs;  // created on first use of each 
 int g_visible = 0;                                // devices this process may use (ntt_init)
 bool g_inited = false;
 
+struct Device;
+int current_device(Device** out);
+
 int do_init(int n_gpus) {
     if (g_inited) {
         if (n_gpus > 0 && n_gpus < g_visible) g_visible = n_gpus;
@@ -148,7 +159,8 @@ int do_init(int n_gpus) {
         return fail(NTT_ERR_DEVICE, "no usable HIP device (this library has no CPU fallback)");
     g_visible = (n_gpus > 0 && n_gpus < count) ? n_gpus : count;
     g_inited = true;
-    return NTT_OK;
+    Device* dev = nullptr;   // per-device set-up of the caller's current device: stream, address of the static scratch
+    return current_device(&dev);
 }
 
 int get_device(int id, Device** out) {
@@ -160,6 +172,15 @@ int get_device(int id, Device** out) {
     HIP_TRY(hipGetDevice(&prev));
     HIP_TRY(hipSetDevice(id));
     HIP_TRY(hipStreamCreate(&dev->stream));
+    {   // with this device current: where its copy of the static scratch array lives
+        void* sp = nullptr;
+        hipError_t e = hipGetSymbolAddress(&sp, HIP_SYMBOL(g_noalloc_scratch));
+        if (e != hipSuccess || !sp) {
+            hipError_t e2 = hipSetDevice(prev); (void)e2;
+            return fail(NTT_ERR_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        }
+        dev->scratch = sp;
+    }
     HIP_TRY(hipSetDevice(prev));
     *out = dev.get();
     g_devs[id] = std::move(dev);
@@ -1046,6 +1067,38 @@ int ntt_poly_multiply_batched_device(const uint32_t* d_a, const uint32_t* d_b, u
     }
     return product_device<uint32_t, uint32_t>(dev, d_a, d_b, d_ab, n, p, batch, a_stride, b_stride, ab_stride, workspace,
                                               workspace_bytes, (hipStream_t)stream);
+}
+
+// Same products as ntt_poly_multiply_batched_device, for callers that may not allocate device memory: every lookup below
+// is a lookup only (no plan is built, no stream or buffer created), and the intermediates go to the static scratch.
+int ntt_poly_multiply_batched_device_noalloc(const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_ab, int n, uint32_t p,
+                                             size_t batch, size_t a_stride, size_t b_stride, size_t ab_stride, void* stream) {
+    int rc = check_args(d_a, d_b, d_ab, n, batch);
+    if (rc != NTT_OK) return rc;
+    if (a_stride < (size_t)n || b_stride < (size_t)n || ab_stride < (size_t)(2 * n - 1)) return fail(NTT_ERR_ARG, "row stride too small");
+    if (!g_inited) return fail(NTT_ERR_DEVICE, "library not initialised: call ntt_init() before the allocation-free entry point");
+    if (batch == 0) return NTT_OK;
+    int id = 0;
+    HIP_TRY(hipGetDevice(&id));
+    auto dit = g_devs.find(id);
+    if (dit == g_devs.end() || !dit->second->scratch)
+        return fail(NTT_ERR_DEVICE, "this device has not been set up: call ntt_init() or any product entry point with it current first");
+    Device* dev = dit->second.get();
+    const int logL = transform_log2(n);
+    auto pit = dev->plans.find(std::make_pair(p, logL));
+    if (pit == dev->plans.end())
+        return fail(NTT_ERR_ARG, "no cached tables for this (n, p) on this device: run one product with the same n and p through "
+                                 "ntt_poly_multiply_batched_device first (it builds them), then call the allocation-free entry point");
+    const Plan& pl = *pit->second;
+    const size_t need = pipeline_workspace_bytes(logL, batch);
+    if (need > NOALLOC_SCRATCH_BYTES) {
+        const size_t per = pipeline_workspace_bytes(logL, 1);
+        return fail(NTT_ERR_WORKSPACE, "batch too large for the static scratch of " + std::to_string(NOALLOC_SCRATCH_BYTES >> 20) +
+                                       " MiB: at most " + std::to_string(NOALLOC_SCRATCH_BYTES / per) + " products of this length per call");
+    }
+    // the column pass writes every word of the scratch it uses before the core reads it: nothing has to be cleared
+    if (pl.h.lazy) return launch_product<true>(pl, d_a, d_b, d_ab, n, batch, a_stride, b_stride, ab_stride, dev->scratch, (hipStream_t)stream);
+    return launch_product<false>(pl, d_a, d_b, d_ab, n, batch, a_stride, b_stride, ab_stride, dev->scratch, (hipStream_t)stream);
 }
 
 int ntt_poly_multiply_batched_device_u64(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_ab, int n, uint64_t p,

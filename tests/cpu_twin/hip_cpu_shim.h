@@ -20,6 +20,8 @@
 #define __shared__ static
 #define __launch_bounds__(...)
 #define __restrict__
+#define __align__(n) __attribute__((aligned(n)))
+#define HIP_SYMBOL(x) (&(x))
 
 struct dim3 {
     unsigned x, y, z;
@@ -107,6 +109,7 @@ inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorInvalidValue; }
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+template <class T> inline hipError_t hipGetSymbolAddress(void** p, T* sym) { *p = (void*)sym; return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
