@@ -315,8 +315,16 @@ def main():
     # launch stream (the headline loop above runs without them).
     kernels = {}
     if not args.no_kernel_events and rank == 0:
+        # (the checks above left the GPU idle: ramp and warm up again, or the pass would time the clock transient)
+        t_ramp = time.perf_counter()
+        while args.ramp_ms > 0 and (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+            for _ in range(8):
+                step()
+            sync()
+        for _ in range(args.warmup):
+            step()
         lib.lib.ntt_profile_enable(1)
-        for _ in range(min(args.steps, 50)):
+        for _ in range(min(args.steps, 100)):
             step()
         sync()
         names = ctypes.create_string_buffer(512)
