@@ -214,8 +214,12 @@ bool prof_event(hipEvent_t* e) {
     return true;
 }
 
+std::mutex g_prof_mutex;   // launches may come from the per-device threads of a multi-device call
+
 int prof_begin(const char* label, hipStream_t st) {
-    if (!g_prof_on || g_prof.size() >= PROF_MAX_RECORDS) return -1;
+    if (!g_prof_on) return -1;
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
+    if (g_prof.size() >= PROF_MAX_RECORDS) return -1;
     const size_t used_before = g_prof_used;
     ProfRec r; r.label = label; r.e0 = nullptr; r.e1 = nullptr; r.closed = false;
     if (!prof_event(&r.e0) || !prof_event(&r.e1) || hipEventRecord(r.e0, st) != hipSuccess) {
@@ -226,7 +230,9 @@ int prof_begin(const char* label, hipStream_t st) {
     return (int)g_prof.size() - 1;
 }
 void prof_end(int slot, hipStream_t st) {
-    if (slot < 0 || (size_t)slot >= g_prof.size()) return;
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
+    if ((size_t)slot >= g_prof.size()) return;
     g_prof[slot].closed = hipEventRecord(g_prof[slot].e1, st) == hipSuccess;
 }
 
@@ -684,13 +690,17 @@ int check_args(const void* a, const void* b, const void* ab, int n, size_t batch
 // The staging copies of large host-pointer calls are memory-bound on the CPU side; a handful of threads that live
 // as long as the library (the analogue of the reference's worker pool, main_pthread.cc:296-441, here only for
 // memcpy) move them at several times the rate of one.
+// Set in the per-device host threads of a multi-device call: their staging copies run in the calling thread (the
+// devices' threads are the parallelism there, and the pool serves one caller at a time).
+thread_local bool t_inline_copies = false;
+
 class CopyPool {
   public:
     static CopyPool& get() { static CopyPool* p = new CopyPool(); return *p; }  // never destroyed: workers may outlive main
     void copy(void* dst, const void* src, size_t bytes, size_t piece = (size_t)1 << 20) {
         int parts = (int)((bytes + piece - 1) / piece);
         if (parts > (int)workers_.size() + 1) parts = (int)workers_.size() + 1;
-        if (parts <= 1) { memcpy(dst, src, bytes); return; }
+        if (parts <= 1 || t_inline_copies) { memcpy(dst, src, bytes); return; }
         const size_t per = (((bytes + parts - 1) / parts) + 63) & ~(size_t)63;  // ceil: parts * per >= bytes, no tail is lost
         run(parts, [=](int i) {
             const size_t lo = (size_t)i * per;
@@ -703,7 +713,7 @@ class CopyPool {
     void for_range(size_t count, size_t grain, const std::function<void(int, size_t, size_t)>& fn) {
         int parts = (int)((count + grain - 1) / grain);
         if (parts > (int)workers_.size() + 1) parts = (int)workers_.size() + 1;
-        if (parts <= 1) { fn(0, 0, count); return; }
+        if (parts <= 1 || t_inline_copies) { fn(0, 0, count); return; }
         const size_t per = (((count + parts - 1) / parts) + 15) & ~(size_t)15;  // ceil: parts * per >= count
         run(parts, [&](int i) {
             const size_t lo = (size_t)i * per;
@@ -921,38 +931,66 @@ int run_host_sharded(const T* a, const T* b, T* ab, int n, size_t batch, int n_g
         return run_host_pipelined(dev, a, b, ab, n, p, batch, run);
     }
     const size_t per = (batch + G - 1) / G;
-    std::vector<Device*> used;
-    FinishList finish;
-    for (int g = 0; g < G; ++g) {
-        const size_t lo = (size_t)g * per, hi = lo + per < batch ? lo + per : batch;
-        if (lo >= hi) break;
-        Device* dev = nullptr;
-        // a single-device call runs on the caller's current device, a sharded one on devices 0..G-1
-        rc = get_device(G == 1 ? home : g, &dev);
-        if (rc != NTT_OK) break;
+    // rows [lo, hi) on one device: staged copy in, product, copy out enqueued on the device's stream
+    auto shard_one = [&](Device* dev, size_t lo, size_t hi, FinishList& finish) -> int {
         bool narrowed = false;
         if constexpr (sizeof(T) == 8) {
             if (narrow_p) {
-                rc = run_host_shard_narrow(dev, (const uint64_t*)a + lo * n, (const uint64_t*)b + lo * n,
-                                           (uint64_t*)ab + lo * (size_t)(2 * n - 1), n, hi - lo, narrow_p, finish, &narrowed);
-                if (rc != NTT_OK) break;
+                int r = run_host_shard_narrow(dev, (const uint64_t*)a + lo * n, (const uint64_t*)b + lo * n,
+                                              (uint64_t*)ab + lo * (size_t)(2 * n - 1), n, hi - lo, narrow_p, finish, &narrowed);
+                if (r != NTT_OK) return r;
             }
         }
-        if (!narrowed) rc = run_host_shard(dev, a + lo * n, b + lo * n, ab + lo * (size_t)(2 * n - 1), n, hi - lo, run, finish);
-        if (rc != NTT_OK) break;
-        used.push_back(dev);
-    }
-    int rc2 = NTT_OK;
-    for (Device* dev : used) {
+        if (narrowed) return NTT_OK;
+        return run_host_shard(dev, a + lo * n, b + lo * n, ab + lo * (size_t)(2 * n - 1), n, hi - lo, run, finish);
+    };
+    auto sync_dev = [](Device* dev) -> int {
         hipError_t e = hipSetDevice(dev->id);
         if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
-        if (e != hipSuccess && rc2 == NTT_OK) rc2 = fail(NTT_ERR_DEVICE, std::string("stream sync: ") + hipGetErrorString(e));
+        return e == hipSuccess ? NTT_OK : fail(NTT_ERR_DEVICE, std::string("stream sync: ") + hipGetErrorString(e));
+    };
+    if (G == 1) {  // on the caller's current device, staging copies spread over the copy pool
+        Device* dev = nullptr;
+        if ((rc = get_device(home, &dev)) != NTT_OK) return rc;
+        FinishList finish;
+        rc = shard_one(dev, 0, batch, finish);
+        const int rc2 = sync_dev(dev);   // also after an error: nothing may still be in flight towards the caller's memory
+        hipError_t e0 = hipSetDevice(home);
+        (void)e0;
+        if (rc == NTT_OK && rc2 == NTT_OK)
+            for (auto& f : finish) f();
+        return rc != NTT_OK ? rc : rc2;
     }
+    // Several devices (0..G-1): one host thread per device stages, launches, waits and copies back its own shard, so
+    // that the host copies and the PCIe transfers of all devices overlap -- the per-prime parallel region of the
+    // reference (main_openMP.cc:394-397) with devices in the place of thread teams.
+    std::vector<Device*> devs((size_t)G, nullptr);
+    for (int g = 0; g < G; ++g)
+        if ((rc = get_device(g, &devs[(size_t)g])) != NTT_OK) return rc;   // created here: the device table is not shared state of the threads
+    struct Outcome { int rc = NTT_OK; std::string err; };
+    std::vector<Outcome> outcome((size_t)G);
+    std::vector<std::thread> threads;
+    for (int g = 0; g < G; ++g) {
+        const size_t lo = (size_t)g * per, hi = lo + per < batch ? lo + per : batch;
+        if (lo >= hi) break;
+        threads.emplace_back([&, g, lo, hi] {
+            t_inline_copies = true;
+            FinishList finish;
+            int r = shard_one(devs[(size_t)g], lo, hi, finish);
+            const int r2 = sync_dev(devs[(size_t)g]);
+            if (r == NTT_OK) r = r2;
+            if (r == NTT_OK)
+                for (auto& f : finish) f();
+            outcome[(size_t)g].rc = r;
+            if (r != NTT_OK) outcome[(size_t)g].err = g_err;   // the message lives in this thread's slot
+        });
+    }
+    for (auto& t : threads) t.join();
     hipError_t e0 = hipSetDevice(home);
     (void)e0;
-    if (rc == NTT_OK && rc2 == NTT_OK)
-        for (auto& f : finish) f();
-    return rc != NTT_OK ? rc : rc2;
+    for (const Outcome& o : outcome)
+        if (o.rc != NTT_OK) return fail(o.rc, o.err);
+    return NTT_OK;
 }
 
 int run_host_shard_narrow(Device* dev, const uint64_t* a, const uint64_t* b, uint64_t* ab, int n, size_t batch, uint32_t p,

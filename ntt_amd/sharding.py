@@ -15,8 +15,16 @@ def shard_range(total, rank, world):
 
 
 def crt_prime_owner(prime_index, world):
-    """Rank that computes CRT prime `prime_index` (round-robin, main_mpi_CRT.cc:470,499)."""
+    """Rank that computes CRT prime `prime_index` in the reference's own placement (round-robin, main_mpi_CRT.cc:470,499).
+    With four primes it keeps at most four ranks busy; crt_unit_range is the placement this package uses."""
     return prime_index % world
+
+
+def crt_unit_range(batch, rank, world):
+    """Contiguous run [lo, hi) of the 4 * batch residue products (unit = prime * batch + row) computed by `rank`.
+    world = 1: everything; 2: two primes each; 4: one prime each; 8: one prime per pair of ranks, the batch halved inside
+    the pair; any batch >= world / 4 keeps every rank busy."""
+    return shard_range(4 * batch, rank, world)
 
 
 def max_over_ranks(value, dist=None, device=None):

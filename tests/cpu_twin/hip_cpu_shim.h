@@ -17,7 +17,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __shared__ static
+#define __shared__ static thread_local   /* one workgroup at a time per host thread */
 #define __launch_bounds__(...)
 #define __restrict__
 #define __align__(n) __attribute__((aligned(n)))
@@ -40,7 +40,7 @@ struct State {
     const std::function<void()>* body = nullptr;
     int current = 0;
 };
-inline State& st() { static State s; return s; }
+inline State& st() { static thread_local State s; return s; }   // launches from different host threads do not meet
 
 inline void fiber_entry() {
     State& s = st();
@@ -103,9 +103,12 @@ enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNoDevice = 100 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "shim error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-inline hipError_t hipSetDevice(int) { return hipSuccess; }
-inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+// NTT_TWIN_DEVICES=k makes the stand-in report k devices (all of them host memory), so that the multi-device host logic runs
+inline int shim_device_count() { const char* e = getenv("NTT_TWIN_DEVICES"); const int k = e ? atoi(e) : 1; return k >= 1 && k <= 64 ? k : 1; }
+inline int& shim_current_device() { static thread_local int d = 0; return d; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = shim_device_count(); return hipSuccess; }
+inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= shim_device_count()) return hipErrorInvalidValue; shim_current_device() = d; return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = shim_current_device(); return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorInvalidValue; }
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }

@@ -375,3 +375,50 @@ def test_staged_copies_keep_the_tail_of_odd_sized_batches(twin, tmp_path, worker
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "RESULT True" in r.stdout, r.stdout[-500:]
+
+
+MULTI_DEVICE_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from ntt_amd._binding import NttLibrary, NttError
+from oracle_binding import Oracle
+lib = NttLibrary(LIB); orc = Oracle()
+lib.init(0)
+assert lib.lib.ntt_device_count() == 3
+rng = np.random.default_rng(31)
+p, P = 998244353, 1337006139375617
+ok = True
+for n, batch, gpus in ((2048, 7, 3), (2048, 7, 2), (512, 2, 3), (16384, 5, 3), (100, 1, 3), (4096, 9, 0)):
+    a = rng.integers(0, p, (batch, n), dtype=np.uint32); b = rng.integers(0, p, (batch, n), dtype=np.uint32)
+    got = lib.multiply_batched(a, b, p, gpus)
+    got64 = lib.multiply_batched_u64(a.astype(np.uint64), b.astype(np.uint64), p, gpus)
+    for r in range(batch):
+        want = orc.ntt_multiply(a[r], b[r], p) if n & (n - 1) == 0 else orc.schoolbook_u64(a[r], b[r], p)
+        ok = ok and np.array_equal(got[r].astype(np.uint64), want) and np.array_equal(got64[r], want)
+A = rng.integers(0, P, (5, 1024), dtype=np.uint64); B = rng.integers(0, P, (5, 1024), dtype=np.uint64)
+got = lib.multiply_batched_u64(A, B, P, 3)                      # four-prime route, shards of 2, 2, 1 rows
+ok = ok and all(np.array_equal(got[r], orc.crt_ntt_multiply(A[r], B[r], P)) for r in range(5))
+U = rng.integers(0, 2**64, (4, 256), dtype=np.uint64)            # unreduced values: not narrowed, reduced on the device
+got = lib.multiply_batched_u64(U, U, p, 3)
+ok = ok and all(np.array_equal(got[r], orc.ntt_multiply(U[r] % p, U[r] % p, p)) for r in range(4))
+err = ""
+try:
+    lib.multiply_batched(A[:, :8].astype(np.uint32), A[:, :8].astype(np.uint32), 1000000007, 3)   # refused before any device work
+except NttError as e:
+    err = str(e)
+print("RESULT", ok, "NTT-friendly" in err)
+'''
+
+
+def test_batches_sharded_over_several_devices_inside_the_library(twin, tmp_path):
+    """ntt_poly_multiply_batched(_u64)(..., n_gpus): the stand-in reports three devices, so the per-device host threads, uneven
+    shards (3 + 3 + 1, 2 + 2 + 1), batches smaller than the device count and the narrowing path all run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "multidev.py"
+    script.write_text(f"ROOT = {root!r}\nLIB = {twin.path!r}\n" + MULTI_DEVICE_WORKER)
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, NTT_TWIN_DEVICES="3"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RESULT True True" in r.stdout, r.stdout[-500:]

@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from ntt_amd.sharding import crt_prime_owner, shard_range
+from ntt_amd.sharding import crt_prime_owner, crt_unit_range, shard_range
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -19,7 +19,7 @@ import numpy as np
 import torch, torch.distributed as dist
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from ntt_amd._binding import NttLibrary
-from ntt_amd.sharding import shard_range, crt_prime_owner, max_over_ranks, gather_rows
+from ntt_amd.sharding import shard_range, crt_prime_owner, crt_unit_range, max_over_ranks, gather_rows
 from oracle_binding import Oracle
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -64,6 +64,16 @@ got3 = crt_multiply_distributed(lib, A3, B3, P, dist, torch.device("cpu"))
 ok3 = all(np.array_equal(got3[r], orc.crt_ntt_multiply(A3[r], B3[r], P)) for r in range(3))
 got4 = crt_multiply_distributed(lib, A[:1000], B[:1000], P, dist, torch.device("cpu"))
 ok3 = ok3 and np.array_equal(got4, orc.schoolbook_u64(A[:1000], B[:1000], P))
+for bt, nn in ((1, 4), (2, 1), (5, 8), (world, 512), (2 * world + 1, 64)):   # batches below, at and above the rank count
+    A5 = rng.integers(0, P, (bt, nn), dtype=np.uint64); B5 = rng.integers(0, P, (bt, nn), dtype=np.uint64)
+    got5 = crt_multiply_distributed(lib, A5, B5, P, dist, torch.device("cpu"), all_ranks=False)
+    if rank == 0:
+        ok3 = ok3 and all(np.array_equal(got5[r], orc.schoolbook_u64(A5[r], B5[r], P)) for r in range(bt))
+    else:
+        ok3 = ok3 and got5 is None
+busy = crt_unit_range(2, rank, world)
+ok3 = ok3 and (busy[1] > busy[0] or world > 8)          # two rows keep up to eight ranks busy
+flag = torch.tensor([1 if ok3 else 0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN); ok3 = bool(flag.item())
 # 4. one long product by the four-step transform in the 64-bit field, matrix sharded over the ranks,
 #    all-to-all between the two transform axes (3 per product)
 from ntt_amd.fourstep import poly_multiply_fourstep
@@ -96,11 +106,16 @@ def test_shard_range_partitions_exactly():
     assert [crt_prime_owner(i, 2) for i in range(4)] == [0, 1, 0, 1]
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+    # (prime, row) units: one prime per rank at world 4, one prime per pair at world 8 with the rows split inside the pair
+    assert [crt_unit_range(1, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 3), (3, 4)]
+    assert [crt_unit_range(2, r, 8) for r in range(8)] == [(r, r + 1) for r in range(8)]
+    assert crt_unit_range(64, 3, 8) == (96, 128)   # rank 3: second half of prime 1's rows
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_gloo_ranks_shard_batch_crt_primes_and_fourstep(tmp_path, world):
-    """world = 2: two primes per rank; world = 4: one prime per rank and a 4-way all-to-all in the four-step product."""
+    """world = 2: two primes per rank; world = 4: one prime per rank and a 4-way all-to-all in the four-step product;
+    world = 8: one prime per pair of ranks with the batch split inside the pair."""
     import json
     script = tmp_path / "worker.py"
     script.write_text(f"ROOT = {ROOT!r}\n" + WORKER)
