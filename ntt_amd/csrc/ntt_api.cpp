@@ -105,10 +105,15 @@ struct Plan {
     CoreTables core{};
 };
 
-// 64-bit field: constants and the two-level twiddle tables for the root of order 2^log_root
+// 64-bit field: constants of both arithmetic flavours, the two-level twiddle tables for the root of order
+// 2^log_root and the round tables of the LDS kernels.  fp: the double-precision flavour serves this modulus
+// (p <= 1.5e15); the tables then hold balanced doubles instead of Montgomery forms.
 struct Plan64 {
+    bool fp = false;
     Field64Consts fc{};
+    FieldDConsts fd{};
     Twiddle64 tw{};
+    RoundTables64 rt{};
     int log_root = 0;
     DevBuf tables;
 };
@@ -462,6 +467,33 @@ bool modulus64_test(uint64_t p, int log_root, std::string* why) {
 
 uint64_t h_mont64(uint64_t x, uint64_t p) { return (uint64_t)(((u128)(x % p) << 64) % p); }
 
+// NTT_FIELD64=int keeps every modulus on the integer flavour (A/B measurements and tests of that path)
+bool fieldd_allowed() {
+    static const bool v = [] { const char* e = getenv("NTT_FIELD64"); return !(e && strcmp(e, "int") == 0); }();
+    return v;
+}
+
+// constant c (plain residue) in the form the plan's multiply wants, as a 64-bit word: Montgomery form, or the bits of the
+// balanced double (|c| <= p/2)
+uint64_t tw_word(const Plan64& pl, uint64_t c) {
+    const uint64_t p = pl.fc.p;
+    c %= p;
+    if (!pl.fp) return h_mont64(c, p);
+    const double d = c > p / 2 ? -(double)(p - c) : (double)c;
+    uint64_t bits;
+    memcpy(&bits, &d, sizeof bits);
+    return bits;
+}
+template <class F> typename F::W scale_arg(uint64_t word);
+template <> uint64_t scale_arg<Field64>(uint64_t word) { return word; }
+template <> double scale_arg<FieldD>(uint64_t word) { double d; memcpy(&d, &word, sizeof d); return d; }
+template <class F> const typename F::Consts& consts_of(const Plan64& pl);
+template <> const Field64Consts& consts_of<Field64>(const Plan64& pl) { return pl.fc; }
+template <> const FieldDConsts& consts_of<FieldD>(const Plan64& pl) { return pl.fd; }
+
+// factor the pointwise product leaves on the data (undone by the final scale): 2^-64 in Montgomery arithmetic, none in doubles
+uint64_t pointwise_compensation(const Plan64& pl) { return pl.fp ? 1 : pl.fc.r1; }
+
 int get_plan64(Device* dev, uint64_t p, int log_root, Plan64** out) {
     auto key = std::make_pair(p, log_root);
     auto it = dev->plans64.find(key);
@@ -470,6 +502,7 @@ int get_plan64(Device* dev, uint64_t p, int log_root, Plan64** out) {
     if (!modulus64_ok(p, log_root, &why)) return fail(NTT_ERR_MODULUS, why);
     std::unique_ptr<Plan64> pl(new Plan64());
     pl->log_root = log_root;
+    pl->fp = fieldd_allowed() && (double)p <= FIELDD_MAX_P;
     Field64Consts& fc = pl->fc;
     fc.p = p;
     uint64_t inv = p;  // Newton iteration for p^-1 mod 2^64
@@ -477,98 +510,272 @@ int get_plan64(Device* dev, uint64_t p, int log_root, Plan64** out) {
     fc.np = 0 - inv;
     fc.r1 = h_mont64(1, p);
     fc.r2 = h_mont64(fc.r1, p);
+    FieldDConsts& fd = pl->fd;
+    fd.p = (double)p;
+    fd.u = 1.0 / (double)p;
+    {
+        const uint64_t c40 = (1ull << 40) % p;
+        fd.c40 = c40 > p / 2 ? -(double)(p - c40) : (double)c40;
+    }
+    auto balanced = [&](uint64_t c) { return c > p / 2 ? -(double)(p - c) : (double)c; };
     const uint64_t wL = h_powmod(3, (p - 1) >> log_root, p);
-    for (int e = 0; e < 8; ++e) { fc.root16F[e] = 0; fc.root16I[e] = 0; }
+    for (int e = 0; e < 8; ++e) { fc.root16F[e] = 0; fc.root16I[e] = 0; fd.root16F[e] = 0; fd.root16I[e] = 0; }
     if (log_root >= 4) {
         const uint64_t w16 = h_powmod(wL, 1ull << (log_root - 4), p), w16i = h_powmod(w16, p - 2, p);
         uint64_t a = 1, b = 1;
         for (int e = 0; e < 8; ++e) {
             fc.root16F[e] = h_mont64(a, p); fc.root16I[e] = h_mont64(b, p);
+            fd.root16F[e] = balanced(a); fd.root16I[e] = balanced(b);
             a = h_mulmod(a, w16, p); b = h_mulmod(b, w16i, p);
         }
     } else {  // shorter transforms only use the low exponents that exist: w16^(e * 16/2^Q) with 2^Q <= root order
         for (int e = 0; e < 8; ++e) {
             if ((e << log_root) % 16 == 0) {
-                fc.root16F[e] = h_mont64(h_powmod(wL, (uint64_t)(e << log_root) / 16, p), p);
-                fc.root16I[e] = h_mont64(h_powmod(wL, (1ull << log_root) - (uint64_t)(e << log_root) / 16, p), p);
+                const uint64_t a = h_powmod(wL, (uint64_t)(e << log_root) / 16, p);
+                const uint64_t b = h_powmod(wL, (1ull << log_root) - (uint64_t)(e << log_root) / 16, p);
+                fc.root16F[e] = h_mont64(a, p); fc.root16I[e] = h_mont64(b, p);
+                fd.root16F[e] = balanced(a); fd.root16I[e] = balanced(b);
             }
         }
     }
+    // image: [two-level table w0 | w1 | round tables forward b = 5..min(12, log_root) | the same, inverse]
     const int t0 = log_root > LOCAL64_LOG ? log_root - LOCAL64_LOG : 0;
     const size_t n0 = (size_t)1 << t0, n1 = (size_t)1 << (log_root - t0);
     std::vector<uint64_t> img(n0 + n1);
     uint64_t a = 1;
-    for (size_t i = 0; i < n0; ++i) { img[i] = h_mont64(a, p); a = h_mulmod(a, wL, p); }
+    for (size_t i = 0; i < n0; ++i) { img[i] = tw_word(*pl, a); a = h_mulmod(a, wL, p); }
     const uint64_t wstep = h_powmod(wL, n0, p);
     a = 1;
-    for (size_t i = 0; i < n1; ++i) { img[n0 + i] = h_mont64(a, p); a = h_mulmod(a, wstep, p); }
+    for (size_t i = 0; i < n1; ++i) { img[n0 + i] = tw_word(*pl, a); a = h_mulmod(a, wstep, p); }
+    size_t off_f[14] = {0}, off_i[14] = {0};
+    const int bmax = log_root < 12 ? log_root : 12;
+    for (int dir = 0; dir < 2; ++dir) {
+        for (int b = 5; b <= bmax; ++b) {
+            (dir ? off_i : off_f)[b] = img.size();
+            uint64_t wB = h_powmod(wL, 1ull << (log_root - b), p);      // root of order 2^b
+            if (dir) wB = h_powmod(wB, p - 2, p);
+            const size_t sub = (size_t)1 << (b - 4);
+            img.resize(img.size() + (sub << 4));
+            uint64_t* T = img.data() + (dir ? off_i : off_f)[b];
+            for (int pos = 0; pos < 16; ++pos) {
+                const uint64_t stepw = h_powmod(wB, (uint64_t)bitrev(pos, 4), p);   // w_B^bitrev4(pos)
+                uint64_t v = 1;
+                for (size_t j = 0; j < sub; ++j) { T[(j << 4) + pos] = tw_word(*pl, v); v = h_mulmod(v, stepw, p); }
+            }
+        }
+    }
     int rc = pl->tables.ensure(img.size() * sizeof(uint64_t));
     if (rc != NTT_OK) return rc;
     HIP_TRY(hipMemcpy(pl->tables.ptr, img.data(), img.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    pl->tw.w0 = (const uint64_t*)pl->tables.ptr;
-    pl->tw.w1 = pl->tw.w0 + n0;
+    const uint64_t* base = (const uint64_t*)pl->tables.ptr;
+    pl->tw.w0 = base;
+    pl->tw.w1 = base + n0;
     pl->tw.t0 = t0;
     pl->tw.logtab = log_root;
+    for (int b = 0; b < 14; ++b) {
+        pl->rt.f[b] = (b >= 5 && b <= bmax) ? base + off_f[b] : nullptr;
+        pl->rt.i[b] = (b >= 5 && b <= bmax) ? base + off_i[b] : nullptr;
+    }
     *out = pl.get();
     dev->plans64[key] = std::move(pl);
     return NTT_OK;
 }
 
-template <bool INV>
-int launch_strided64(const Plan64& pl, uint64_t* d, int q, const Pass64& g, hipStream_t st) {
-    const unsigned grid = (unsigned)((g.n_threads + 255) / 256);
-    switch (q) {
-        case 1: NTT_LAUNCH_P("k64_strided", (k64_strided<1, INV>), dim3(grid), dim3(256), st, d, g, pl.fc, pl.tw); break;
-        case 2: NTT_LAUNCH_P("k64_strided", (k64_strided<2, INV>), dim3(grid), dim3(256), st, d, g, pl.fc, pl.tw); break;
-        case 3: NTT_LAUNCH_P("k64_strided", (k64_strided<3, INV>), dim3(grid), dim3(256), st, d, g, pl.fc, pl.tw); break;
-        default: NTT_LAUNCH_P("k64_strided", (k64_strided<4, INV>), dim3(grid), dim3(256), st, d, g, pl.fc, pl.tw); break;
+unsigned grid_for(uint64_t count) { return (unsigned)((count + 255) / 256); }
+
+// ---- passes of one transform along the middle axis of [outer][2^log_len][inner] ----
+struct Step64 {
+    enum Kind { TILE, REG, LOCAL, SMALL } kind;
+    int cur;   // log2 of the block length the pass starts from (forward direction)
+    int q;     // levels it performs
+};
+
+bool is_pow2(uint64_t x) { return x && (x & (x - 1)) == 0; }
+
+std::vector<Step64> plan_steps(int log_len, size_t inner, size_t outer) {
+    std::vector<Step64> steps;
+    int stop = 0;
+    Step64 last{Step64::LOCAL, 0, 0};
+    if (inner == 1) {
+        stop = log_len < LOCAL64_LOG ? log_len : LOCAL64_LOG;
+        const bool whole_chunks = (((uint64_t)outer << log_len) & (LOCAL64_N - 1)) == 0;
+        last = Step64{whole_chunks ? Step64::LOCAL : Step64::SMALL, stop, stop};
+    }
+    for (int cur = log_len; cur > stop;) {
+        const int remaining = cur - stop;
+        int q = 0;
+        if (remaining >= TILE64_MIN_LOGR && is_pow2(inner)) {
+            const int npass = (remaining + TILE64_MAX_LOGR - 1) / TILE64_MAX_LOGR;
+            q = (remaining + npass - 1) / npass;
+            if (remaining - q > 0 && remaining - q < TILE64_MIN_LOGR) q = remaining - TILE64_MIN_LOGR;   // leave a tileable rest
+            const uint64_t columns = ((uint64_t)1 << (cur - q)) * inner;
+            if (q < TILE64_MIN_LOGR || q > TILE64_MAX_LOGR || columns % ((uint64_t)TILE64_N >> q) != 0) q = 0;
+        }
+        if (q) {
+            steps.push_back({Step64::TILE, cur, q});
+        } else {
+            q = remaining < 4 ? remaining : 4;
+            steps.push_back({Step64::REG, cur, q});
+        }
+        cur -= q;
+    }
+    if (stop) steps.push_back(last);
+    return steps;
+}
+
+struct TileExtra {           // fusions of a product's first and last pass
+    const uint64_t* src = nullptr; uint64_t src_valid = 0;               // forward: raw operands, zero beyond src_valid
+    uint64_t* out = nullptr; uint64_t n_out = 0; uint64_t scale_word = 0; // inverse: scaled canonical output
+    const uint64_t* other = nullptr;                                      // inverse local pass: pointwise product first
+};
+
+template <class F>
+int run_step(const Plan64& pl, uint64_t* d, const Step64& s, int log_len, size_t inner, size_t outer, bool inverse,
+             const TileExtra& ex, hipStream_t st) {
+    const typename F::Consts& fc = consts_of<F>(pl);
+    if (s.kind == Step64::TILE || s.kind == Step64::REG) {
+        Pass64 g{};
+        g.cq = (uint64_t)1 << (s.cur - s.q);
+        g.inner = inner;
+        g.n_threads = ((uint64_t)outer << (log_len - s.cur)) * g.cq * inner;
+        g.tw_stride = (uint64_t)1 << (pl.log_root - s.cur);
+        g.tw_mask = ((uint64_t)1 << pl.log_root) - 1;
+        g.q = s.q;
+        g.src_valid = ex.src_valid;
+        if (s.kind == Step64::REG) {
+            if (g.n_threads / 256 >= (1ull << 31)) return fail(NTT_ERR_ARG, "transform too large for one launch");
+            const unsigned grid = (unsigned)((g.n_threads + 255) / 256);
+#define NTT_REG_CASE(Q)                                                                                              \
+    if (inverse) NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, true>), dim3(grid), dim3(256), st, d, g, fc, pl.tw);  \
+    else NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, false>), dim3(grid), dim3(256), st, d, g, fc, pl.tw)
+            switch (s.q) {
+                case 1: NTT_REG_CASE(1); break;
+                case 2: NTT_REG_CASE(2); break;
+                case 3: NTT_REG_CASE(3); break;
+                default: NTT_REG_CASE(4); break;
+            }
+#undef NTT_REG_CASE
+        } else {
+            int li = 0;
+            while (((uint64_t)1 << li) < inner) ++li;
+            g.log_inner = li;
+            g.tiles_per_block = g.cq * inner / ((uint64_t)TILE64_N >> s.q);
+            const uint64_t tiles = ((uint64_t)outer << (log_len - s.cur)) * g.tiles_per_block;
+            if (tiles >= (1ull << 31)) return fail(NTT_ERR_ARG, "transform too large for one launch");
+            const unsigned grid = (unsigned)tiles;
+            const typename F::W scale = scale_arg<F>(ex.scale_word);
+            if (!inverse) {
+                if (ex.src) NTT_LAUNCH_P("k64_tile", (k64_tile<F, false, true, false>), dim3(grid), dim3(TILE64_T), st, d, ex.src, (uint64_t*)nullptr, (uint64_t)0, scale, g, fc, pl.tw, pl.rt);
+                else NTT_LAUNCH_P("k64_tile", (k64_tile<F, false, false, false>), dim3(grid), dim3(TILE64_T), st, d, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, scale, g, fc, pl.tw, pl.rt);
+            } else {
+                if (ex.out) NTT_LAUNCH_P("k64_tile", (k64_tile<F, true, false, true>), dim3(grid), dim3(TILE64_T), st, d, (const uint64_t*)nullptr, ex.out, ex.n_out, scale, g, fc, pl.tw, pl.rt);
+                else NTT_LAUNCH_P("k64_tile", (k64_tile<F, true, false, false>), dim3(grid), dim3(TILE64_T), st, d, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, scale, g, fc, pl.tw, pl.rt);
+            }
+        }
+    } else if (s.kind == Step64::LOCAL) {
+        const uint64_t n_chunks = ((uint64_t)outer << log_len) >> LOCAL64_LOG;
+        const unsigned grid = (unsigned)(n_chunks < (1u << 20) ? n_chunks : (1u << 20));
+        const typename F::W scale = scale_arg<F>(ex.scale_word);
+        if (!inverse) NTT_LAUNCH_P("k64_local", (k64_local<F, false, false, false>), dim3(grid), dim3(LOCAL64_T), st, d, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, scale, s.q, n_chunks, fc, pl.rt);
+        else if (ex.other) NTT_LAUNCH_P("k64_local", (k64_local<F, true, true, false>), dim3(grid), dim3(LOCAL64_T), st, d, ex.other, (uint64_t*)nullptr, (uint64_t)0, scale, s.q, n_chunks, fc, pl.rt);
+        else NTT_LAUNCH_P("k64_local", (k64_local<F, true, false, false>), dim3(grid), dim3(LOCAL64_T), st, d, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, scale, s.q, n_chunks, fc, pl.rt);
+    } else {
+        const uint64_t n_blocks = (uint64_t)outer << (log_len - s.q);
+        const unsigned grid = (unsigned)(n_blocks < (1u << 20) ? n_blocks : (1u << 20));
+        if (inverse) NTT_LAUNCH_P("k64_small", (k64_small<F, true>), dim3(grid), dim3(256), st, d, s.q, n_blocks, fc, pl.tw);
+        else NTT_LAUNCH_P("k64_small", (k64_small<F, false>), dim3(grid), dim3(256), st, d, s.q, n_blocks, fc, pl.tw);
     }
     HIP_TRY(hipGetLastError());
     return NTT_OK;
 }
 
 // in-place transform along the middle axis of [outer][2^log_len][inner]
-int transform64(const Plan64& pl, uint64_t* d, int log_len, size_t inner, size_t outer, bool inverse, hipStream_t st) {
-    if (log_len > pl.log_root) return fail(NTT_ERR_ARG, "transform longer than the plan's root order");
-    if (log_len == 0 || outer == 0 || inner == 0) return NTT_OK;
-    const int stop = inner == 1 ? (log_len < LOCAL64_LOG ? log_len : LOCAL64_LOG) : 0;
-    struct Step { int cur, q; };
-    std::vector<Step> steps;
-    for (int cur = log_len; cur > stop;) {
-        const int q = cur - stop < 4 ? cur - stop : 4;
-        steps.push_back({cur, q});
-        cur -= q;
-    }
-    auto strided = [&](const Step& s) -> int {
-        Pass64 g;
-        g.cq = (uint64_t)1 << (s.cur - s.q);
-        g.inner = inner;
-        g.n_threads = ((uint64_t)outer << (log_len - s.cur)) * g.cq * inner;
-        g.tw_stride = (uint64_t)1 << (pl.log_root - s.cur);
-        g.tw_mask = ((uint64_t)1 << pl.log_root) - 1;
-        if (g.n_threads / 256 >= (1ull << 31)) return fail(NTT_ERR_ARG, "transform too large for one launch");
-        return inverse ? launch_strided64<true>(pl, d, s.q, g, st) : launch_strided64<false>(pl, d, s.q, g, st);
-    };
-    auto local = [&]() -> int {
-        if (stop == 0) return NTT_OK;
-        const uint64_t n_blocks = (uint64_t)outer << (log_len - stop);
-        const unsigned grid = (unsigned)(n_blocks < (1u << 20) ? n_blocks : (1u << 20));
-        if (inverse) NTT_LAUNCH_P("k64_local", (k64_local<true>), dim3(grid), dim3(256), st, d, stop, n_blocks, pl.fc, pl.tw);
-        else NTT_LAUNCH_P("k64_local", (k64_local<false>), dim3(grid), dim3(256), st, d, stop, n_blocks, pl.fc, pl.tw);
-        HIP_TRY(hipGetLastError());
-        return NTT_OK;
-    };
+template <class F>
+int transform64_f(const Plan64& pl, uint64_t* d, int log_len, size_t inner, size_t outer, bool inverse, hipStream_t st) {
+    const std::vector<Step64> steps = plan_steps(log_len, inner, outer);
+    const TileExtra none;
     int rc;
     if (!inverse) {
-        for (const Step& s : steps) if ((rc = strided(s)) != NTT_OK) return rc;
-        return local();
+        for (const Step64& s : steps) if ((rc = run_step<F>(pl, d, s, log_len, inner, outer, false, none, st)) != NTT_OK) return rc;
+    } else {
+        for (size_t i = steps.size(); i-- > 0;) if ((rc = run_step<F>(pl, d, steps[i], log_len, inner, outer, true, none, st)) != NTT_OK) return rc;
     }
-    if ((rc = local()) != NTT_OK) return rc;
-    for (size_t i = steps.size(); i-- > 0;) if ((rc = strided(steps[i])) != NTT_OK) return rc;
     return NTT_OK;
 }
 
-unsigned grid_for(uint64_t count) { return (unsigned)((count + 255) / 256); }
+int transform64(const Plan64& pl, uint64_t* d, int log_len, size_t inner, size_t outer, bool inverse, hipStream_t st) {
+    if (log_len > pl.log_root) return fail(NTT_ERR_ARG, "transform longer than the plan's root order");
+    if (log_len == 0 || outer == 0 || inner == 0) return NTT_OK;
+    return pl.fp ? transform64_f<FieldD>(pl, d, log_len, inner, outer, inverse, st) : transform64_f<Field64>(pl, d, log_len, inner, outer, inverse, st);
+}
+
+// element-wise kernels, by field
+template <class F>
+void launch_load64(const Plan64& pl, const uint64_t* src, size_t src_stride, uint64_t n, uint64_t* dst, uint64_t len, uint64_t rows, hipStream_t st) {
+    NTT_LAUNCH_P("k64_load", (k64_load<F>), dim3(grid_for(rows * len)), dim3(256), st, src, src_stride, n, dst, len, rows, consts_of<F>(pl));
+}
+void load64(const Plan64& pl, const uint64_t* src, size_t src_stride, uint64_t n, uint64_t* dst, uint64_t len, uint64_t rows, hipStream_t st) {
+    if (pl.fp) launch_load64<FieldD>(pl, src, src_stride, n, dst, len, rows, st); else launch_load64<Field64>(pl, src, src_stride, n, dst, len, rows, st);
+}
+void pointwise64(const Plan64& pl, uint64_t* a, const uint64_t* b, uint64_t count, hipStream_t st) {
+    if (pl.fp) NTT_LAUNCH_P("k64_pointwise", (k64_pointwise<FieldD>), dim3(grid_for(count)), dim3(256), st, a, b, count, pl.fd);
+    else NTT_LAUNCH_P("k64_pointwise", (k64_pointwise<Field64>), dim3(grid_for(count)), dim3(256), st, a, b, count, pl.fc);
+}
+// out[row][i] = canonical(data[row][i] * scale), scale a plain residue
+void finalize64(const Plan64& pl, const uint64_t* data, uint64_t len, uint64_t* out, size_t out_stride, uint64_t n_out, uint64_t rows,
+                uint64_t scale, hipStream_t st) {
+    const uint64_t word = tw_word(pl, scale);
+    if (pl.fp) NTT_LAUNCH_P("k64_finalize", (k64_finalize<FieldD>), dim3(grid_for(rows * n_out)), dim3(256), st, data, len, out, out_stride, n_out, rows, scale_arg<FieldD>(word), pl.fd);
+    else NTT_LAUNCH_P("k64_finalize", (k64_finalize<Field64>), dim3(grid_for(rows * n_out)), dim3(256), st, data, len, out, out_stride, n_out, rows, scale_arg<Field64>(word), pl.fc);
+}
+void twiddle64(const Plan64& pl, uint64_t* d, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0, int row_bits, int rows_bitrev,
+               int inverse, hipStream_t st) {
+    const uint64_t mask = ((uint64_t)1 << pl.log_root) - 1;
+    if (pl.fp) NTT_LAUNCH_P("k64_twiddle", (k64_twiddle<FieldD>), dim3(grid_for(rows * cols)), dim3(256), st, d, rows, cols, row0, col0, row_bits, rows_bitrev, inverse, (uint64_t)1, mask, pl.fd, pl.tw);
+    else NTT_LAUNCH_P("k64_twiddle", (k64_twiddle<Field64>), dim3(grid_for(rows * cols)), dim3(256), st, d, rows, cols, row0, col0, row_bits, rows_bitrev, inverse, (uint64_t)1, mask, pl.fc, pl.tw);
+}
+
+// One product in the field, operands and result in caller memory, two work arrays of L words.  When the first pass of
+// the transform is a tile pass, the operand load (reduction of arbitrary words, zero padding) rides on it, the pointwise
+// product on the first pass of the inverse, and scaling, canonical reduction and the copy to `out` on its last pass.
+template <class F>
+int product64_row(const Plan64& pl, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int logL, uint64_t* wa, uint64_t* wb,
+                  hipStream_t st) {
+    const size_t L = (size_t)1 << logL;
+    const uint64_t p = pl.fc.p;
+    const uint64_t Linv = h_powmod((uint64_t)L % p, p - 2, p);
+    const uint64_t scale = h_mulmod(Linv, pointwise_compensation(pl), p);
+    const std::vector<Step64> steps = plan_steps(logL, 1, 1);
+    int rc;
+    const bool fused = steps.size() >= 2 && steps.front().kind == Step64::TILE && steps.back().kind == Step64::LOCAL;
+    if (!fused) {
+        load64(pl, a, 0, n, wa, L, 1, st);
+        load64(pl, b, 0, n, wb, L, 1, st);
+        if ((rc = transform64_f<F>(pl, wa, logL, 1, 1, false, st)) != NTT_OK) return rc;
+        if ((rc = transform64_f<F>(pl, wb, logL, 1, 1, false, st)) != NTT_OK) return rc;
+        pointwise64(pl, wa, wb, L, st);
+        if ((rc = transform64_f<F>(pl, wa, logL, 1, 1, true, st)) != NTT_OK) return rc;
+        finalize64(pl, wa, L, out, 0, 2 * n - 1, 1, scale, st);
+        HIP_TRY(hipGetLastError());
+        return NTT_OK;
+    }
+    const TileExtra none;
+    for (int side = 0; side < 2; ++side) {
+        uint64_t* w = side ? wb : wa;
+        TileExtra first;
+        first.src = side ? b : a;
+        first.src_valid = n;
+        for (size_t i = 0; i < steps.size(); ++i)
+            if ((rc = run_step<F>(pl, w, steps[i], logL, 1, 1, false, i == 0 ? first : none, st)) != NTT_OK) return rc;
+    }
+    for (size_t i = steps.size(); i-- > 0;) {
+        TileExtra ex;
+        if (i + 1 == steps.size()) ex.other = wb;
+        if (i == 0) { ex.out = out; ex.n_out = 2 * n - 1; ex.scale_word = tw_word(pl, scale); }
+        if ((rc = run_step<F>(pl, wa, steps[i], logL, 1, 1, true, ex, st)) != NTT_OK) return rc;
+    }
+    return NTT_OK;
+}
 
 // whole products in the 64-bit field, one row after the other through one workspace
 int field64_product_device(Device* dev, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint64_t p, size_t batch,
@@ -586,18 +793,10 @@ int field64_product_device(Device* dev, const uint64_t* a, const uint64_t* b, ui
     }
     uint64_t* wa = (uint64_t*)ws;
     uint64_t* wb = wa + L;
-    const uint64_t Linv = h_powmod((uint64_t)L % p, p - 2, p);
-    const uint64_t scale_m = h_mont64(h_mulmod(Linv, pl->fc.r1, p), p);
     for (size_t row = 0; row < batch; ++row) {
-        NTT_LAUNCH_P("k64_load", k64_load, dim3(grid_for(L)), dim3(256), st, a + row * sa, (size_t)0, (uint64_t)n, wa, (uint64_t)L, (uint64_t)1, pl->fc);
-        NTT_LAUNCH_P("k64_load", k64_load, dim3(grid_for(L)), dim3(256), st, b + row * sb, (size_t)0, (uint64_t)n, wb, (uint64_t)L, (uint64_t)1, pl->fc);
-        if ((rc = transform64(*pl, wa, logL, 1, 1, false, st)) != NTT_OK) return rc;
-        if ((rc = transform64(*pl, wb, logL, 1, 1, false, st)) != NTT_OK) return rc;
-        NTT_LAUNCH_P("k64_pointwise", k64_pointwise, dim3(grid_for(L)), dim3(256), st, wa, (const uint64_t*)wb, (uint64_t)L, pl->fc);
-        if ((rc = transform64(*pl, wa, logL, 1, 1, true, st)) != NTT_OK) return rc;
-        NTT_LAUNCH_P("k64_finalize", k64_finalize, dim3(grid_for(2 * n - 1)), dim3(256), st, (const uint64_t*)wa, (uint64_t)L,
-                     out + row * so, (size_t)0, (uint64_t)(2 * n - 1), (uint64_t)1, scale_m, pl->fc);
-        HIP_TRY(hipGetLastError());
+        rc = pl->fp ? product64_row<FieldD>(*pl, a + row * sa, b + row * sb, out + row * so, n, logL, wa, wb, st)
+                    : product64_row<Field64>(*pl, a + row * sa, b + row * sb, out + row * so, n, logL, wa, wb, st);
+        if (rc != NTT_OK) return rc;
     }
     return NTT_OK;
 }
@@ -1280,9 +1479,7 @@ int ntt64_twiddle_device(uint64_t* d_data, uint64_t p, int log_root, size_t rows
     Plan64* pl = nullptr;
     if ((rc = get_plan64(dev, p, log_root, &pl)) != NTT_OK) return rc;
     if (rows == 0 || cols == 0) return NTT_OK;
-    NTT_LAUNCH_P("k64_twiddle", k64_twiddle, dim3(grid_for((uint64_t)rows * cols)), dim3(256), (hipStream_t)stream, d_data,
-                 (uint64_t)rows, (uint64_t)cols, row0, col0, row_bits, rows_bitrev, inverse, (uint64_t)1,
-                 ((uint64_t)1 << log_root) - 1, pl->fc, pl->tw);
+    twiddle64(*pl, d_data, (uint64_t)rows, (uint64_t)cols, row0, col0, row_bits, rows_bitrev, inverse, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return NTT_OK;
 }
@@ -1296,8 +1493,7 @@ int ntt64_pointwise_device(uint64_t* d_a, const uint64_t* d_b, size_t count, uin
     Plan64* pl = nullptr;
     if ((rc = get_plan64(dev, p, log_root, &pl)) != NTT_OK) return rc;
     if (count == 0) return NTT_OK;
-    NTT_LAUNCH_P("k64_pointwise", k64_pointwise, dim3(grid_for(count)), dim3(256), (hipStream_t)stream, d_a, d_b, (uint64_t)count,
-                 pl->fc);
+    pointwise64(*pl, d_a, d_b, (uint64_t)count, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return NTT_OK;
 }
@@ -1312,8 +1508,7 @@ int ntt64_load_device(const uint64_t* d_src, size_t src_stride, size_t n, uint64
     Plan64* pl = nullptr;
     if ((rc = get_plan64(dev, p, log_root, &pl)) != NTT_OK) return rc;
     if (rows == 0 || len == 0) return NTT_OK;
-    NTT_LAUNCH_P("k64_load", k64_load, dim3(grid_for((uint64_t)rows * len)), dim3(256), (hipStream_t)stream, d_src, src_stride,
-                 (uint64_t)n, d_dst, (uint64_t)len, (uint64_t)rows, pl->fc);
+    load64(*pl, d_src, src_stride, (uint64_t)n, d_dst, (uint64_t)len, (uint64_t)rows, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return NTT_OK;
 }
@@ -1330,9 +1525,8 @@ int ntt64_finalize_device(const uint64_t* d_data, size_t len, uint64_t* d_out, s
     if (rows == 0 || n_out == 0) return NTT_OK;
     // scale = L^-1 * R (the R undoes the R^-1 left by the pointwise product), in Montgomery form
     const uint64_t Linv = h_powmod((1ull << log_total) % p, p - 2, p);
-    const uint64_t scale_m = h_mont64(h_mulmod(Linv, pl->fc.r1, p), p);
-    NTT_LAUNCH_P("k64_finalize", k64_finalize, dim3(grid_for((uint64_t)rows * n_out)), dim3(256), (hipStream_t)stream, d_data,
-                 (uint64_t)len, d_out, out_stride, (uint64_t)n_out, (uint64_t)rows, scale_m, pl->fc);
+    finalize64(*pl, d_data, (uint64_t)len, d_out, out_stride, (uint64_t)n_out, (uint64_t)rows,
+               h_mulmod(Linv, pointwise_compensation(*pl), p), (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return NTT_OK;
 }
@@ -1366,8 +1560,7 @@ int ntt_transform_device_u64(uint64_t* d_a, size_t n, size_t batch, int invert, 
             if ((rc = current_device(&dev1)) != NTT_OK) return rc;
             Plan64* pl1 = nullptr;
             if ((rc = get_plan64(dev1, p, 1, &pl1)) != NTT_OK) return rc;
-            NTT_LAUNCH_P("k64_load", k64_load, dim3(grid_for(batch)), dim3(256), (hipStream_t)stream, (const uint64_t*)d_a, (size_t)1,
-                         (uint64_t)1, d_a, (uint64_t)1, (uint64_t)batch, pl1->fc);
+            load64(*pl1, (const uint64_t*)d_a, (size_t)1, (uint64_t)1, d_a, (uint64_t)1, (uint64_t)batch, (hipStream_t)stream);
             HIP_TRY(hipGetLastError());
         }
         return NTT_OK;
@@ -1379,8 +1572,7 @@ int ntt_transform_device_u64(uint64_t* d_a, size_t n, size_t batch, int invert, 
     if ((rc = get_plan64(dev, p, lg, &pl)) != NTT_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const uint64_t total = (uint64_t)batch * n;
-    NTT_LAUNCH_P("k64_load", k64_load, dim3(grid_for(total)), dim3(256), st, (const uint64_t*)d_a, (size_t)n, (uint64_t)n, d_a,
-                 (uint64_t)n, (uint64_t)batch, pl->fc);
+    load64(*pl, (const uint64_t*)d_a, (size_t)n, (uint64_t)n, d_a, (uint64_t)n, (uint64_t)batch, st);
     uint64_t scale = 1;
     if (!invert) {
         if ((rc = transform64(*pl, d_a, lg, 1, batch, false, st)) != NTT_OK) return rc;
@@ -1390,8 +1582,7 @@ int ntt_transform_device_u64(uint64_t* d_a, size_t n, size_t batch, int invert, 
         if ((rc = transform64(*pl, d_a, lg, 1, batch, true, st)) != NTT_OK) return rc;
         scale = h_powmod((uint64_t)n % p, p - 2, p);   // n^-1, as main_naive.cc:132
     }
-    NTT_LAUNCH_P("k64_finalize", k64_finalize, dim3(grid_for(total)), dim3(256), st, (const uint64_t*)d_a, (uint64_t)n, d_a, (size_t)n,
-                 (uint64_t)n, (uint64_t)batch, h_mont64(scale, p), pl->fc);
+    finalize64(*pl, (const uint64_t*)d_a, (uint64_t)n, d_a, (size_t)n, (uint64_t)n, (uint64_t)batch, scale, st);
     HIP_TRY(hipGetLastError());
     return NTT_OK;
 }
@@ -1448,8 +1639,8 @@ int ntt_describe_plan(int n, uint64_t p, char* buf, size_t buf_len) {
     const char* pipe = logL <= 12 ? "k_small" : logL == 13 ? "k_fused8192" : "k_fwd_strided,k_core_mul,k_inv_strided";
     if (route == ROUTE_DIRECT32) s = pipe;
     else if (route == ROUTE_CRT) s = std::string("4x(") + pipe + "),k_crt_merge";
-    else if (route == ROUTE_FIELD64) s = "k64_load,k64_strided,k64_local,k64_pointwise,k64_finalize";
-    else if (route == ROUTE_WIDECRT) s = "k64_load,k64_strided,k64_local,k64_pointwise,k64_finalize,k64_garner";
+    else if (route == ROUTE_FIELD64) s = "k64_tile,k64_local,k64_strided,k64_load,k64_pointwise,k64_finalize";
+    else if (route == ROUTE_WIDECRT) s = "k64_tile,k64_local,k64_strided,k64_load,k64_pointwise,k64_finalize,k64_garner";
     else return fail(NTT_ERR_MODULUS, why);
     snprintf(buf, buf_len, "%s", s.c_str());
     return NTT_OK;

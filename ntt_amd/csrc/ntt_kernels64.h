@@ -1,37 +1,364 @@
-// Kernels over the 64-bit prime field (ntt_field64.h): transforms of any power-of-two
-// length along the middle axis of an [outer][len][inner] array, the building blocks of the
-// four-step product of one very long polynomial pair (single GPU or sharded over ranks with
-// an all-to-all transpose between the two transform axes).
+// Kernels over the 64-bit prime fields (ntt_field64.h): transforms of any power-of-two length along the middle
+// axis of an [outer][len][inner] array, the building blocks of the product of one very long polynomial pair
+// (single GPU, or sharded over ranks with an all-to-all transpose between the two transform axes).
 //
-// Forward = in-place decimation in frequency (natural order in, bit-reversed order out),
-// inverse = the mirror (bit-reversed in, natural out, unscaled).  A length-2^l transform is a
-// chain of strided radix-2^q register passes (q <= 4) from the largest block down; when
-// inner == 1 the last 12 levels run inside LDS on contiguous 4096-value blocks.
+// Forward = in-place decimation in frequency (natural order in, bit-reversed order out), inverse = the mirror
+// (bit-reversed in, natural out, unscaled).  A length-2^l transform is a chain of passes over memory, from the
+// largest block down; every pass multiplies by the twiddles that join it to the next one:
 //
-// Replaces, for moduli that are themselves NTT-friendly, the reference's replicate-and-
-// all-reduce distributed transform (main_mpi_t.cc:139-291) and extends the serial transform
-// (main_naive.cc:96-137) beyond the 2-adicity of any 32-bit prime.
+//   k64_tile     a workgroup of 512 threads holds a tile of R = 2^5..2^9 rows x W = 8192/R adjacent columns in
+//                LDS (64 KiB) and runs all log2 R levels on it: radix-16 rounds in registers, one LDS exchange
+//                between rounds.  Rows are `step` elements apart in memory, columns adjacent (>= 128 bytes).
+//   k64_local    contiguous blocks of up to 4096 values (the last 12 levels of an axis with unit stride): copied
+//                into LDS, radix-16 rounds, copied out; optionally the pointwise product of two spectra on the
+//                way in (the first pass of the inverse transform of a product).
+//   k64_strided  register-only radix 2..16 pass for shapes the tiles do not fit (odd inner extents, tiny axes).
+//   k64_small    radix-2 stages in LDS for short contiguous axes in arrays smaller than one k64_local chunk.
+//
+// Every kernel is a template over the field (Field64: Montgomery integers for p < 2^60; FieldD: exact
+// double-precision arithmetic for p <= 1.5e15, about four times fewer issue cycles per butterfly).
+//
+// Replaces, for moduli that are themselves NTT-friendly, the reference's replicate-and-all-reduce distributed
+// transform (main_mpi_t.cc:139-291) and extends the serial transform (main_naive.cc:96-137) beyond the 2-adicity
+// of any 32-bit prime.
 #pragma once
 #include "ntt_field64.h"
 
 namespace nttamd {
 
-constexpr int LOCAL64_LOG = 12;  // log2 of the largest LDS-resident block (4096 x 8 B = 32 KiB)
+constexpr int LOCAL64_LOG = 12;              // log2 of a k64_local chunk (4096 x 8 B = 32 KiB of LDS)
+constexpr int LOCAL64_N = 1 << LOCAL64_LOG;
+constexpr int LOCAL64_T = 256;               // threads of k64_local: 16 values each
+constexpr int TILE64_LOG = 13;               // log2 of a k64_tile tile (8192 x 8 B = 64 KiB of LDS)
+constexpr int TILE64_N = 1 << TILE64_LOG;
+constexpr int TILE64_T = 512;                // threads of k64_tile: 16 values each
+constexpr int TILE64_MIN_LOGR = 5, TILE64_MAX_LOGR = 9;
 
-// one strided pass: blocks of length Lb = cq << Q; thread = (block, column jq < cq, inner index c);
-// the 2^Q rows jq + cq*r are transformed in registers, then multiplied by w_Lb^(jq * bitrev_Q(r)).
+// Twiddles between the radix-16 rounds inside a tile or chunk: for block length Bk = 2^b (b = 5..12),
+// f[b][j*16 + pos] = w_Bk^(j * bitrev4(pos)), j < Bk/16 (i[b]: the inverse powers), in the field's twiddle form.
+struct RoundTables64 {
+    const uint64_t* f[14];
+    const uint64_t* i[14];
+};
+
+// one pass over blocks of length Lb = cq << q along the axis: a "column" is (jq < cq, c < inner); its 2^q rows are
+// cq*inner elements apart; afterwards (forward) / beforehand (inverse) row k is multiplied by w_Lb^(+-jq * bitrev_q(k)).
 struct Pass64 {
     uint64_t cq;        // columns per block
     uint64_t inner;     // contiguous inner extent S
-    uint64_t n_threads; // blocks * cq * inner
+    uint64_t n_threads; // k64_strided: blocks * cq * inner
     uint64_t tw_stride; // (table root order) / Lb : exponent scale to the table's root
     uint64_t tw_mask;   // table root order - 1
+    // k64_tile only
+    int q;              // log2 rows
+    int log_inner;      // inner is a power of two there
+    uint64_t tiles_per_block;   // cq*inner / W
+    uint64_t src_valid; // first pass of a product reading caller data: elements of the source beyond this index are zero
 };
 
-template <int Q, bool INVERSE>
-__global__ void __launch_bounds__(256) k64_strided(uint64_t* data, Pass64 g, Field64Consts fc, Twiddle64 tw) {
+// ---------------------------------------------------------------------------
+// register transforms on 2^Q consecutive entries of a 16-entry array, entries OFF .. OFF + 2^Q - 1
+// (fixed roots w16^e from the field constants; DIF: natural in, bit-reversed out; DIT: the mirror)
+// ---------------------------------------------------------------------------
+template <class F, int Q, int OFF>
+NTT_HD void dif_sub(typename F::V (&x)[16], const F& f, const typename F::W (&root)[8]) {
+    constexpr int N = 1 << Q;
+    static_for<0, Q>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        constexpr int h = N >> (s + 1);
+        static_for<0, N>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr ((i & h) == 0) {
+                constexpr int e = ((i & (h - 1)) << s) << (4 - Q);
+                if constexpr (e == 0) f.dif1(x[OFF + i], x[OFF + i + h]);
+                else f.dif(x[OFF + i], x[OFF + i + h], root[e]);
+            }
+        });
+    });
+}
+template <class F, int Q, int OFF>
+NTT_HD void dit_sub(typename F::V (&x)[16], const F& f, const typename F::W (&root)[8]) {
+    constexpr int N = 1 << Q;
+    static_for<0, Q>([&](auto S) {
+        constexpr int s = Q - 1 - decltype(S)::value;
+        constexpr int h = N >> (s + 1);
+        static_for<0, N>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr ((i & h) == 0) {
+                constexpr int e = ((i & (h - 1)) << s) << (4 - Q);
+                if constexpr (e == 0) f.dit1(x[OFF + i], x[OFF + i + h]);
+                else f.dit(x[OFF + i], x[OFF + i + h], root[e]);
+            }
+        });
+    });
+}
+// the 16 entries as 16 >> Q independent blocks of 2^Q
+template <class F, int Q>
+NTT_HD void dif_blocks(typename F::V (&x)[16], const F& f, const typename F::W (&root)[8]) {
+    static_for<0, (16 >> Q)>([&](auto Bk) { dif_sub<F, Q, (decltype(Bk)::value << Q)>(x, f, root); });
+}
+template <class F, int Q>
+NTT_HD void dit_blocks(typename F::V (&x)[16], const F& f, const typename F::W (&root)[8]) {
+    static_for<0, (16 >> Q)>([&](auto Bk) { dit_sub<F, Q, (decltype(Bk)::value << Q)>(x, f, root); });
+}
+template <class F>
+NTT_HD void dif_blocks_rt(int q, typename F::V (&x)[16], const F& f, const typename F::W (&root)[8]) {
+    switch (q) {
+        case 1: dif_blocks<F, 1>(x, f, root); break;
+        case 2: dif_blocks<F, 2>(x, f, root); break;
+        case 3: dif_blocks<F, 3>(x, f, root); break;
+        default: dif_blocks<F, 4>(x, f, root); break;
+    }
+}
+template <class F>
+NTT_HD void dit_blocks_rt(int q, typename F::V (&x)[16], const F& f, const typename F::W (&root)[8]) {
+    switch (q) {
+        case 1: dit_blocks<F, 1>(x, f, root); break;
+        case 2: dit_blocks<F, 2>(x, f, root); break;
+        case 3: dit_blocks<F, 3>(x, f, root); break;
+        default: dit_blocks<F, 4>(x, f, root); break;
+    }
+}
+
+template <class F>
+NTT_HD void load_roots(typename F::W (&rF)[8], typename F::W (&rI)[8], const typename F::Consts& c) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { rF[e] = c.root16F[e]; rI[e] = c.root16I[e]; }
+}
+
+NTT_HD uint64_t bitrev64(uint64_t x, int bits) {
+    uint64_t r = 0;
+    for (int b = 0; b < bits; ++b) r |= ((x >> b) & 1ull) << (bits - 1 - b);
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// k64_tile: R = 2^q rows (q = 5..9) x W = 8192 >> q adjacent columns per workgroup.
+//   thread t: column x = t % W, group grp = t / W (grp < R/16).
+//   round over blocks of 2^b rows (b = q, q-4, ... > 4): rows blk*2^b + j + m*2^(b-4), m < 16, (blk, j) from grp
+//   last round (blocks of 2^ql <= 16 rows): rows 16 grp + i, i < 16.
+// SRC_RAW (forward only): the first round reads caller data (any 64-bit words, zero beyond g.src_valid elements)
+//   from `src` instead of `data`.
+// FINAL (inverse only): the last round multiplies by `scale`, reduces to [0,p) and writes the elements below
+//   n_out to `out` instead of `data`.
+// ---------------------------------------------------------------------------
+template <class F, bool INVERSE, bool SRC_RAW, bool FINAL>
+__global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint64_t* src, uint64_t* out, uint64_t n_out,
+                                                     typename F::W scale, Pass64 g, typename F::Consts fc, Twiddle64 tw,
+                                                     RoundTables64 rt) {
+    typedef typename F::V V;
+    typedef typename F::W W;
+    __shared__ V lds[TILE64_N];
+    const F f(fc);
+    W rF[8], rI[8];
+    load_roots<F>(rF, rI, fc);
+    const int q = g.q;
+    const int logW = TILE64_LOG - q;
+    const int t = threadIdx.x;
+    const int x = t & ((1 << logW) - 1), grp = t >> logW;
+    const uint64_t tile = blockIdx.x;
+    const uint64_t blk_g = tile / g.tiles_per_block, xt = tile % g.tiles_per_block;
+    const uint64_t step = g.cq * g.inner;                       // elements between rows
+    const uint64_t col = (xt << logW) + (uint64_t)x;            // fused column (jq, c) inside the block
+    const uint64_t origin = (blk_g << q) * step + col;          // element offset of row 0 of this column
+    const uint64_t jq = col >> g.log_inner;
+    const int ql = ((q - 1) & 3) + 1;                           // levels of the last (smallest) round, 1..4
+    V v[16];
+
+    auto boundary_exp = [&](int row) -> uint64_t {   // exponent of the pass twiddle for the frequency this row holds
+        const uint64_t k = bitrev64((uint64_t)row, q);
+        const uint64_t e = (jq * k * g.tw_stride) & g.tw_mask;
+        return INVERSE ? ((0 - e) & g.tw_mask) : e;
+    };
+
+    if (!INVERSE) {
+        bool first = true;
+        for (int b = q; b > 4; b -= 4) {         // rounds over blocks of 2^b rows
+            const int sub = 1 << (b - 4);
+            const int blk = grp >> (b - 4), j = grp & (sub - 1);
+            const int row0 = (blk << b) + j;
+            if (first) {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    const uint64_t idx = origin + (uint64_t)(row0 + m * sub) * step;
+                    if (SRC_RAW) {
+                        const bool inside = idx < g.src_valid;
+                        const uint64_t raw = src[inside ? idx : 0];
+                        v[m] = f.from_raw(inside ? raw : 0);
+                    } else {
+                        v[m] = f.from_mem(data[idx]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) v[m] = lds[((row0 + m * sub) << logW) + x];
+            }
+            dif_blocks<F, 4>(v, f, rF);
+            const uint64_t* T = rt.f[b] + ((size_t)j << 4);
+#pragma unroll
+            for (int pos = 1; pos < 16; ++pos) v[pos] = f.twiddled(v[pos], f.tw_from_mem(T[pos]));
+#pragma unroll
+            for (int m = 0; m < 16; ++m) lds[((row0 + m * sub) << logW) + x] = v[m];
+            __syncthreads();
+            first = false;
+        }
+        // last round: rows 16*grp + i, blocks of 2^ql rows; then the pass twiddle and the store
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = lds[(((grp << 4) + i) << logW) + x];
+        dif_blocks_rt<F>(ql, v, f, rF);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (grp << 4) + i;
+            const uint64_t e = boundary_exp(row);
+            V r = v[i];
+            if (e != 0) r = f.twiddled(r, twiddle_pow(tw, f, e));
+            data[origin + (uint64_t)row * step] = f.to_mem(r);
+        }
+    } else {
+        // first round of the inverse = mirror of the last forward round
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (grp << 4) + i;
+            const uint64_t e = boundary_exp(row);
+            V r = f.from_mem(data[origin + (uint64_t)row * step]);
+            if (e != 0) r = f.twiddled(r, twiddle_pow(tw, f, e));
+            v[i] = r;
+        }
+        dit_blocks_rt<F>(ql, v, f, rI);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lds[(((grp << 4) + i) << logW) + x] = v[i];
+        __syncthreads();
+        for (int b = ql + 4; b <= q; b += 4) {
+            const int sub = 1 << (b - 4);
+            const int blk = grp >> (b - 4), j = grp & (sub - 1);
+            const int row0 = (blk << b) + j;
+            const uint64_t* T = rt.i[b] + ((size_t)j << 4);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const V r = lds[((row0 + m * sub) << logW) + x];
+                v[m] = m ? f.twiddled(r, f.tw_from_mem(T[m])) : r;
+            }
+            dit_blocks<F, 4>(v, f, rI);
+            if (b < q) {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) lds[((row0 + m * sub) << logW) + x] = v[m];
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    const uint64_t idx = origin + (uint64_t)(row0 + m * sub) * step;
+                    if (FINAL) {
+                        if (idx < n_out) out[idx] = f.canon(f.twiddled(v[m], scale));
+                    } else {
+                        data[idx] = f.to_mem(v[m]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k64_local: chunks of 4096 consecutive values holding 4096 >> m complete blocks of 2^m values each (m = 1..12);
+// all m levels inside LDS.  LDS slot of element e is e ^ ((e >> 4) & 15), which keeps the three access patterns
+// (copy in/out by consecutive threads, rounds with a stride of 2^(b-4), 16 consecutive values per thread) spread
+// over all banks.  MUL (inverse only): the chunk starts as the pointwise product of `data` and `other`.
+// FINAL (inverse only): multiply by `scale`, canonical, elements below n_out to `out`.
+// ---------------------------------------------------------------------------
+NTT_HD int local_slot(int e) { return e ^ ((e >> 4) & 15); }
+
+template <class F, bool INVERSE, bool MUL, bool FINAL>
+__global__ void __launch_bounds__(LOCAL64_T) k64_local(uint64_t* data, const uint64_t* other, uint64_t* out, uint64_t n_out,
+                                                       typename F::W scale, int m, uint64_t n_chunks,
+                                                       typename F::Consts fc, RoundTables64 rt) {
+    typedef typename F::V V;
+    typedef typename F::W W;
+    __shared__ V lds[LOCAL64_N];
+    const F f(fc);
+    W rF[8], rI[8];
+    load_roots<F>(rF, rI, fc);
+    const int t = threadIdx.x;
+    const int ql = ((m - 1) & 3) + 1;
+    V v[16];
+    for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        uint64_t* base = data + chunk * (uint64_t)LOCAL64_N;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = t + LOCAL64_T * i;
+            V r = f.from_mem(base[e]);
+            if (MUL) r = f.mulpw(r, f.from_mem(other[chunk * (uint64_t)LOCAL64_N + e]));
+            lds[local_slot(e)] = r;
+        }
+        __syncthreads();
+        if (!INVERSE) {
+            for (int b = m; b > 4; b -= 4) {
+                const int sub = 1 << (b - 4);
+                const int blk = t >> (b - 4), j = t & (sub - 1);
+                const int e0 = (blk << b) + j;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = lds[local_slot(e0 + k * sub)];
+                dif_blocks<F, 4>(v, f, rF);
+                const uint64_t* T = rt.f[b] + ((size_t)j << 4);
+#pragma unroll
+                for (int pos = 1; pos < 16; ++pos) v[pos] = f.twiddled(v[pos], f.tw_from_mem(T[pos]));
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[local_slot(e0 + k * sub)] = v[k];
+                __syncthreads();
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = lds[local_slot((t << 4) + i)];
+            dif_blocks_rt<F>(ql, v, f, rF);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lds[local_slot((t << 4) + i)] = v[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = lds[local_slot((t << 4) + i)];
+            dit_blocks_rt<F>(ql, v, f, rI);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lds[local_slot((t << 4) + i)] = v[i];
+            for (int b = ql + 4; b <= m; b += 4) {
+                __syncthreads();
+                const int sub = 1 << (b - 4);
+                const int blk = t >> (b - 4), j = t & (sub - 1);
+                const int e0 = (blk << b) + j;
+                const uint64_t* T = rt.i[b] + ((size_t)j << 4);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const V r = lds[local_slot(e0 + k * sub)];
+                    v[k] = k ? f.twiddled(r, f.tw_from_mem(T[k])) : r;
+                }
+                dit_blocks<F, 4>(v, f, rI);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[local_slot(e0 + k * sub)] = v[k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = t + LOCAL64_T * i;
+            const V r = lds[local_slot(e)];
+            if (FINAL) {
+                const uint64_t idx = chunk * (uint64_t)LOCAL64_N + e;
+                if (idx < n_out) out[idx] = f.canon(f.twiddled(r, scale));
+            } else {
+                base[e] = f.to_mem(r);
+            }
+        }
+        __syncthreads();   // the next chunk overwrites the LDS
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k64_strided: register-only pass, radix 2^Q (Q <= 4), one thread per column; any inner extent.
+// ---------------------------------------------------------------------------
+template <class F, int Q, bool INVERSE>
+__global__ void __launch_bounds__(256) k64_strided(uint64_t* data, Pass64 g, typename F::Consts fc, Twiddle64 tw) {
+    typedef typename F::V V;
+    typedef typename F::W W;
     constexpr int R = 1 << Q;
-    const Field64 f(fc);
+    const F f(fc);
+    W rF[8], rI[8];
+    load_roots<F>(rF, rI, fc);
     const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (tid >= g.n_threads) return;
     const uint64_t c = tid % g.inner;
@@ -39,65 +366,43 @@ __global__ void __launch_bounds__(256) k64_strided(uint64_t* data, Pass64 g, Fie
     const uint64_t jq = rest % g.cq, blk = rest / g.cq;
     uint64_t* base = data + ((blk * g.cq * R + jq) * g.inner + c);
     const uint64_t step = g.cq * g.inner;
-    uint64_t x[R];
+    V x[16];
 #pragma unroll
-    for (int r = 0; r < R; ++r) x[r] = base[(uint64_t)r * step];
+    for (int r = 0; r < R; ++r) x[r] = f.from_mem(base[(uint64_t)r * step]);
     if (!INVERSE) {
-        // DIF stages, compile-time twiddles w_{2^Q}^e = w16^(e * 16/2^Q)
-        static_for<0, Q>([&](auto S) {
-            constexpr int s = decltype(S)::value;
-            constexpr int h = R >> (s + 1);
-            static_for<0, R>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                if constexpr ((i & h) == 0) {
-                    constexpr int e = ((i & (h - 1)) << s) << (4 - Q);
-                    if constexpr (e == 0) f.dif1(x[i], x[i + h]);
-                    else f.dif(x[i], x[i + h], fc.root16F[e]);
-                }
-            });
-        });
+        dif_sub<F, Q, 0>(x, f, rF);
         static_for<1, R>([&](auto P) {
             constexpr int pos = decltype(P)::value;
             constexpr int k = bitrev(pos, Q);
             const uint64_t e = (jq * (uint64_t)k * g.tw_stride) & g.tw_mask;
-            x[pos] = f.mulw(x[pos], twiddle_pow(tw, f, e));
+            if (e != 0) x[pos] = f.twiddled(x[pos], twiddle_pow(tw, f, e));
         });
     } else {
         static_for<1, R>([&](auto P) {
             constexpr int pos = decltype(P)::value;
             constexpr int k = bitrev(pos, Q);
             const uint64_t e = (0 - jq * (uint64_t)k * g.tw_stride) & g.tw_mask;  // negative exponent
-            x[pos] = f.mulw(x[pos], twiddle_pow(tw, f, e));
+            if (e != 0) x[pos] = f.twiddled(x[pos], twiddle_pow(tw, f, e));
         });
-        static_for<0, Q>([&](auto S) {
-            constexpr int s = Q - 1 - decltype(S)::value;
-            constexpr int h = R >> (s + 1);
-            static_for<0, R>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                if constexpr ((i & h) == 0) {
-                    constexpr int e = ((i & (h - 1)) << s) << (4 - Q);
-                    if constexpr (e == 0) f.dit1(x[i], x[i + h]);
-                    else f.dit(x[i], x[i + h], fc.root16I[e]);
-                }
-            });
-        });
+        dit_sub<F, Q, 0>(x, f, rI);
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) base[(uint64_t)r * step] = INVERSE ? x[r] : f.csub(x[r], f.B);
+    for (int r = 0; r < R; ++r) base[(uint64_t)r * step] = f.to_mem(x[r]);
 }
 
-// contiguous blocks of 2^m <= 4096 values: all m stages in LDS.  Stage twiddles are powers of the
-// 2^m-th root, i.e. table exponents that are multiples of (root order)/2^m -- one lookup each.
-template <bool INVERSE>
-__global__ void __launch_bounds__(256) k64_local(uint64_t* data, int m, uint64_t n_blocks, Field64Consts fc, Twiddle64 tw) {
-    __shared__ uint64_t lds[1 << LOCAL64_LOG];
-    const Field64 f(fc);
+// contiguous blocks of 2^m <= 4096 values, radix-2 stages in LDS with a barrier per stage: the fall-back for arrays
+// that do not fill whole k64_local chunks.
+template <class F, bool INVERSE>
+__global__ void __launch_bounds__(256) k64_small(uint64_t* data, int m, uint64_t n_blocks, typename F::Consts fc, Twiddle64 tw) {
+    typedef typename F::V V;
+    __shared__ V lds[LOCAL64_N];
+    const F f(fc);
     const int N = 1 << m, half = N >> 1, t = threadIdx.x, T = blockDim.x;
     const uint64_t scale = (uint64_t)1 << (tw.logtab - m);
     const uint64_t mask = ((uint64_t)1 << tw.logtab) - 1;
     for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         uint64_t* src = data + blk * (uint64_t)N;
-        for (int i = t; i < N; i += T) lds[i] = src[i];
+        for (int i = t; i < N; i += T) lds[i] = f.from_mem(src[i]);
         __syncthreads();
         if (!INVERSE) {
             for (int s = 0; s < m; ++s) {
@@ -105,7 +410,7 @@ __global__ void __launch_bounds__(256) k64_local(uint64_t* data, int m, uint64_t
                 for (int k = t; k < half; k += T) {
                     const int j = k & (h - 1), i = ((k - j) << 1) + j;
                     const uint64_t e = ((uint64_t)(j << s) * scale) & mask;
-                    uint64_t u = lds[i], v = lds[i + h];
+                    V u = lds[i], v = lds[i + h];
                     if (e == 0) f.dif1(u, v); else f.dif(u, v, twiddle_pow(tw, f, e));
                     lds[i] = u; lds[i + h] = v;
                 }
@@ -117,54 +422,53 @@ __global__ void __launch_bounds__(256) k64_local(uint64_t* data, int m, uint64_t
                 for (int k = t; k < half; k += T) {
                     const int j = k & (h - 1), i = ((k - j) << 1) + j;
                     const uint64_t e = (0 - (uint64_t)(j << s) * scale) & mask;
-                    uint64_t u = lds[i], v = lds[i + h];
+                    V u = lds[i], v = lds[i + h];
                     if (e == 0) f.dit1(u, v); else f.dit(u, v, twiddle_pow(tw, f, e));
                     lds[i] = u; lds[i + h] = v;
                 }
                 __syncthreads();
             }
         }
-        for (int i = t; i < N; i += T) src[i] = lds[i];
+        for (int i = t; i < N; i += T) src[i] = f.to_mem(lds[i]);
         __syncthreads();
     }
 }
 
-// dst[row][i] = i < n ? src[row][i] mod p : 0   (zero padding + reduction of arbitrary 64-bit input)
+// dst[row][i] = i < n ? src[row][i] mod p : 0   (zero padding + reduction of arbitrary 64-bit input; canonical words)
+template <class F>
 __global__ void __launch_bounds__(256) k64_load(const uint64_t* src, size_t src_stride, uint64_t n, uint64_t* dst, uint64_t len,
-                                                uint64_t rows, Field64Consts fc) {
-    const Field64 f(fc);
+                                                uint64_t rows, typename F::Consts fc) {
+    const F f(fc);
     const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (tid >= rows * len) return;
     const uint64_t row = tid / len, i = tid % len;
-    dst[tid] = i < n ? f.reduce(src[row * src_stride + i], fc.r2) : 0;
+    dst[tid] = i < n ? f.canon(f.from_raw(src[row * src_stride + i])) : 0;
 }
 
-// a[i] = a[i] * b[i] * R^-1  (values < 4p in, [0,2p) out)
-__global__ void __launch_bounds__(256) k64_pointwise(uint64_t* a, const uint64_t* b, uint64_t count, Field64Consts fc) {
-    const Field64 f(fc);
+// a[i] = a[i] * b[i] (times the field's pointwise factor: 2^-64 for Field64, 1 for FieldD)
+template <class F>
+__global__ void __launch_bounds__(256) k64_pointwise(uint64_t* a, const uint64_t* b, uint64_t count, typename F::Consts fc) {
+    const F f(fc);
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < count) a[i] = f.mulw(f.csub(a[i], f.B), f.csub(b[i], f.B));
+    if (i < count) a[i] = f.to_mem(f.mulpw(f.from_mem(a[i]), f.from_mem(b[i])));
 }
 
 // data[r][c] *= w^(+-(row0 + bitrev?(r)) * (col0 + c)) for a rows x cols tile of the four-step
 // matrix; w = root of order 2^log_total.  ROWS_BITREV: row r of the tile holds frequency
 // bitrev(row0 + r, row_bits) (the layout a forward transform along the row axis leaves).
+template <class F>
 __global__ void __launch_bounds__(256) k64_twiddle(uint64_t* data, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0,
                                                    int row_bits, int rows_bitrev, int inverse, uint64_t tw_stride,
-                                                   uint64_t tw_mask, Field64Consts fc, Twiddle64 tw) {
-    const Field64 f(fc);
+                                                   uint64_t tw_mask, typename F::Consts fc, Twiddle64 tw) {
+    const F f(fc);
     const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (tid >= rows * cols) return;
     const uint64_t r = tid / cols, c = tid % cols;
     uint64_t k = row0 + r;
-    if (rows_bitrev) {
-        uint64_t rev = 0;
-        for (int b = 0; b < row_bits; ++b) rev |= ((k >> b) & 1ull) << (row_bits - 1 - b);
-        k = rev;
-    }
+    if (rows_bitrev) k = bitrev64(k, row_bits);
     uint64_t e = (k * (col0 + c) * tw_stride) & tw_mask;
     if (inverse) e = (0 - e) & tw_mask;
-    data[tid] = f.mulw(f.csub(data[tid], f.B), twiddle_pow(tw, f, e));
+    data[tid] = f.to_mem(f.twiddled(f.from_mem(data[tid]), twiddle_pow(tw, f, e)));
 }
 
 // in-place bit-reversal permutation of every row of 2^bits values (the reference's reverse(), main_naive.cc:82-95):
@@ -174,8 +478,7 @@ __global__ void __launch_bounds__(256) k64_bitrev(uint64_t* data, int bits, uint
     const uint64_t len = (uint64_t)1 << bits;
     if (tid >= rows * len) return;
     const uint64_t row = tid >> bits, i = tid & (len - 1);
-    uint64_t rev = 0;
-    for (int b = 0; b < bits; ++b) rev |= ((i >> b) & 1ull) << (bits - 1 - b);
+    const uint64_t rev = bitrev64(i, bits);
     if (i < rev) {
         uint64_t* r = data + row * len;
         const uint64_t t = r[i];
@@ -184,14 +487,15 @@ __global__ void __launch_bounds__(256) k64_bitrev(uint64_t* data, int bits, uint
     }
 }
 
-// out[row][i] = canonical(data[row][i] * scale) for i < n_out   (scale_m = Montgomery form of the scale)
+// out[row][i] = canonical(data[row][i] * scale) for i < n_out
+template <class F>
 __global__ void __launch_bounds__(256) k64_finalize(const uint64_t* data, uint64_t len, uint64_t* out, size_t out_stride,
-                                                    uint64_t n_out, uint64_t rows, uint64_t scale_m, Field64Consts fc) {
-    const Field64 f(fc);
+                                                    uint64_t n_out, uint64_t rows, typename F::W scale, typename F::Consts fc) {
+    const F f(fc);
     const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (tid >= rows * n_out) return;
     const uint64_t row = tid / n_out, i = tid % n_out;
-    out[row * out_stride + i] = f.csub(f.mulw(f.csub(data[row * len + i], f.B), scale_m), f.p);
+    out[row * out_stride + i] = f.canon(f.twiddled(f.from_mem(data[row * len + i]), scale));
 }
 
 // ---------------------------------------------------------------------------

@@ -28,11 +28,20 @@ enum Op {
     OP_REM128 = 14,       // same through the 64-bit-field file's copy (rem128)
     OP_CANON_INV_LZ = 15, // in0 = x in [0,4p)                    -> Field<true>::canon_inv
     OP_SUB_LZ = 16,       // in0 = u | v << 32 (both < 2p)        -> Field<true>::sub
+    // double-precision field: values travel as signed 64-bit integers
+    OP_FD_MULW = 17,      // in0 = x, in1 = w                     -> FieldD::mulw(x, w)
+    OP_FD_REDUCE = 18,    // in0 = x                              -> FieldD::reduce(x)
+    OP_FD_FROM_RAW = 19,  // in0 = any 64-bit word                -> FieldD::from_raw
+    OP_FD_MEM = 20,       // in0 = x                              -> out = to_mem(x), out2 = canon(x)
+    OP_FD_FROM_MEM = 21,  // in0 = stored word (< 2^52)           -> from_mem
+    OP_FD_DIF = 22,       // in0 = u, in1 = v, in2 = w            -> out = u', out2 = v'
+    OP_FD_DIT = 23,
 };
 
 struct PrimConsts {
     FieldConsts fc;
     Field64Consts fc64;
+    FieldDConsts fd;
     uint64_t d, v;
     int shift;
 };
@@ -44,6 +53,8 @@ __global__ void k_prims(int op, const uint64_t* in0, const uint64_t* in1, const 
     const Field<true> fl(c.fc);
     const Field<false> fn(c.fc);
     const Field64 f64(c.fc64);
+    const FieldD fdd(c.fd);
+    const double dx = (double)(int64_t)in0[i], dy = in1 ? (double)(int64_t)in1[i] : 0.0, dz = in2 ? (double)(int64_t)in2[i] : 0.0;
     const uint64_t x = in0[i], y = in1 ? in1[i] : 0, z = in2 ? in2[i] : 0;
     uint64_t r = 0, r2 = 0;
     uint32_t u = (uint32_t)x, w = (uint32_t)(x >> 32);
@@ -65,6 +76,13 @@ __global__ void k_prims(int op, const uint64_t* in0, const uint64_t* in1, const 
         case OP_REM128: r = rem128(x, y, c.d, c.v, c.shift); break;
         case OP_CANON_INV_LZ: r = fl.canon_inv((uint32_t)x); break;
         case OP_SUB_LZ: r = fl.sub(u, w); break;
+        case OP_FD_MULW: r = (uint64_t)(int64_t)fdd.mulw(dx, dy); break;
+        case OP_FD_REDUCE: r = (uint64_t)(int64_t)fdd.reduce(dx); break;
+        case OP_FD_FROM_RAW: r = (uint64_t)(int64_t)fdd.from_raw(x); break;
+        case OP_FD_MEM: r = fdd.to_mem(dx); r2 = fdd.canon(dx); break;
+        case OP_FD_FROM_MEM: r = (uint64_t)(int64_t)fdd.from_mem(x); break;
+        case OP_FD_DIF: { double a = dx, b = dy; fdd.dif(a, b, dz); r = (uint64_t)(int64_t)a; r2 = (uint64_t)(int64_t)b; break; }
+        case OP_FD_DIT: { double a = dx, b = dy; fdd.dit(a, b, dz); r = (uint64_t)(int64_t)a; r2 = (uint64_t)(int64_t)b; break; }
     }
     out[i] = r;
     if (out2) out2[i] = r2;
@@ -86,4 +104,7 @@ extern "C" void prims_consts_fill(PrimConsts* c, uint32_t p32, uint32_t np32, ui
     c->fc.p = p32; c->fc.np = np32; c->fc.r1 = r1_32; c->fc.r2 = r2_32;
     c->fc64.p = p64; c->fc64.np = np64; c->fc64.r1 = r1_64; c->fc64.r2 = r2_64;
     c->d = d; c->v = v; c->shift = shift;
+    c->fd.p = (double)p64; c->fd.u = 1.0 / (double)p64;
+    const uint64_t c40 = (1ull << 40) % p64;
+    c->fd.c40 = c40 > p64 / 2 ? -(double)(p64 - c40) : (double)c40;
 }

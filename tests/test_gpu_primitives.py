@@ -14,7 +14,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 (OP_REDC_LAZY, OP_MULW_LZ, OP_MULW_NLZ, OP_REDUCE64_LZ, OP_REDUCE64_NLZ, OP_DIF_LZ, OP_DIF_NLZ, OP_DIT_LZ, OP_DIT_NLZ, OP_F64_MULW,
- OP_F64_REDUCE, OP_F64_DIF, OP_F64_DIT, OP_REM_2BY1, OP_REM128, OP_CANON_INV_LZ, OP_SUB_LZ) = range(17)
+ OP_F64_REDUCE, OP_F64_DIF, OP_F64_DIT, OP_REM_2BY1, OP_REM128, OP_CANON_INV_LZ, OP_SUB_LZ, OP_FD_MULW, OP_FD_REDUCE, OP_FD_FROM_RAW,
+ OP_FD_MEM, OP_FD_FROM_MEM, OP_FD_DIF, OP_FD_DIT) = range(24)
 
 
 class Prims:
@@ -162,6 +163,54 @@ def test_64_bit_field_multiply_and_reduction(prims, p):
     for a, b, x, y, w in zip(g1, g2, xs4, ys4, wm):
         t = y * w * Rinv
         assert a < 4 * p and b < 4 * p and a % p == (x + t) % p and b % p == (x - t) % p
+
+
+def _signed(v):
+    return [x - (1 << 64) if x >= 1 << 63 else x for x in v]
+
+
+@pytest.mark.parametrize("p", [1337006139375617, 998244353, 7340033, 1499999999999989])
+def test_double_precision_field_is_exact_at_its_range_limits(prims, p):
+    """FieldD (exact integer arithmetic in doubles, moduli up to 1.5e15): every primitive against Python integers at the
+    edges of the ranges its butterflies rely on -- |x| up to 2.5 p into a multiply with |w| up to 0.6 p, anything below 2^52
+    into a reduction -- plus the memory format (reduced value + p) and the canonical store."""
+    rng = np.random.default_rng(p % 991)
+    c = prims.consts(p64=p)
+    half, big = p // 2, int(2.5 * p)
+    def rnd(lo, hi, k):
+        return [int(v) + lo for v in rng.integers(0, hi - lo, k, dtype=np.uint64)]
+    xs = [0, 1, -1, big, -big, big - 1, p, -p, half, -half, p - 1, 1 - p] + rnd(-big, big, 2000)
+    wmax = int(0.6 * p)
+    ws = [wmax, -wmax, wmax, -wmax, half, -half, 1, -1, half, half, -half, half + 1] + rnd(-wmax, wmax, 2000)
+    got = _signed(prims.run(OP_FD_MULW, c, [x % (1 << 64) for x in xs], [w % (1 << 64) for w in ws]))
+    assert all(abs(g) <= 1.25 * p + 2 and (g - x * w) % p == 0 for g, x, w in zip(got, xs, ws))
+    lim = (1 << 52) - 1
+    xr = [0, lim, -lim, p, -p, half, half + 1, -half - 1, 3 * half] + rnd(-lim, lim, 2000)
+    got = _signed(prims.run(OP_FD_REDUCE, c, [x % (1 << 64) for x in xr]))
+    assert all(abs(g) <= half + 1 and (g - x) % p == 0 for g, x in zip(got, xr))
+    raw = [0, 1, p - 1, p, p + 1, (1 << 40) - 1, 1 << 40, (1 << 52), (1 << 63), (1 << 64) - 1, (1 << 64) - 2] + \
+          [int(v) for v in rng.integers(0, 1 << 64, 2000, dtype=np.uint64)]
+    got = _signed(prims.run(OP_FD_FROM_RAW, c, raw))
+    assert all(abs(g) <= half + 1 and (g - x) % p == 0 for g, x in zip(got, raw))
+    # memory format and canonical store, for every value a kernel may hold (|x| < 2^52)
+    m, cn = prims.run(OP_FD_MEM, c, [x % (1 << 64) for x in xr], two=True)
+    assert all(half <= a <= 3 * half + 2 and (a - x) % p == 0 and b == x % p for a, b, x in zip(m, cn, xr))
+    back = _signed(prims.run(OP_FD_FROM_MEM, c, m))
+    assert all(abs(g) <= half + 1 and (g - x) % p == 0 for g, x in zip(back, xr))
+    canon_words = [0, 1, p - 1, 2 * p - 1, p] + [int(v) for v in rng.integers(0, 2 * p, 500, dtype=np.uint64)]   # words other kernels store
+    back = _signed(prims.run(OP_FD_FROM_MEM, c, canon_words))
+    assert all(abs(g) <= p and (g - x) % p == 0 for g, x in zip(back, canon_words))
+    # butterflies: forward inputs up to 1.25 p, inverse inputs up to 1.75 p / 2.5 p
+    b125, b175 = int(1.25 * p), int(1.75 * p)
+    us = [b125, -b125, b125, -b125] + rnd(-b125, b125, 1000); vs = [b125, -b125, -b125, b125] + rnd(-b125, b125, 1000)
+    wt = [wmax, -wmax, wmax, -wmax] + rnd(-wmax, wmax, 1000)
+    g1, g2 = prims.run(OP_FD_DIF, c, [x % (1 << 64) for x in us], [x % (1 << 64) for x in vs], [x % (1 << 64) for x in wt], two=True)
+    for a, b, u, v, w in zip(_signed(g1), _signed(g2), us, vs, wt):
+        assert abs(a) <= half + 1 and abs(b) <= b125 + 2 and (a - (u + v)) % p == 0 and (b - (u - v) * w) % p == 0
+    xs2 = [lim, -lim, b175, -b175] + rnd(-b175, b175, 1000); ys2 = [big, -big, big, -big] + rnd(-big, big, 1000)
+    g1, g2 = prims.run(OP_FD_DIT, c, [x % (1 << 64) for x in xs2], [x % (1 << 64) for x in ys2], [x % (1 << 64) for x in wt], two=True)
+    for a, b, x, y, w in zip(_signed(g1), _signed(g2), xs2, ys2, wt):
+        assert abs(a) <= b175 + 3 and abs(b) <= b175 + 3 and (a - (x + y * w)) % p == 0 and (b - (x - y * w)) % p == 0
 
 
 @pytest.mark.parametrize("p", [2, 3, 1337006139375617, (1 << 63) - 25, 1 << 63, (1 << 64) - 59, (1 << 64) - 1, (1 << 32) + 15, 998244353])
