@@ -90,9 +90,13 @@ def valu_roofline(kernel, batch, avg_ms):
     try:
         with open(os.path.join(ROOT, "profiles", "valu_issue.json")) as f:
             iss = json.load(f)
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
-        with open(pmcs[-1]) as f:
-            pmc = json.load(f)
+        pmc, used = None, None
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):   # newest profile that has this kernel
+            with open(path) as f:
+                cand = json.load(f)
+            if kernel in cand and "SQ_INSTS_VALU" in cand[kernel]:
+                pmc, used = cand, path
+                break
         insts = pmc[kernel]["SQ_INSTS_VALU"] * batch / iss.get("pmc_batch", 256)
         mix = iss["kernels"][kernel]["multiply_class_fraction"]
         cyc = mix * iss["cycles_per_wave_inst"]["multiply_class"] + (1 - mix) * iss["cycles_per_wave_inst"]["plain"]
@@ -101,7 +105,7 @@ def valu_roofline(kernel, batch, avg_ms):
         return {"kernel": kernel, "wave_insts_per_launch": insts, "multiply_class_fraction": mix,
                 "issue_cycles_per_wave_inst": cyc, "peak_wave_insts_per_s": peak, "achieved_wave_insts_per_s": achieved,
                 "frac": achieved / peak,
-                "source": f"profiles/{os.path.basename(pmcs[-1])} + profiles/valu_issue.json (static)"}
+                "source": f"profiles/{os.path.basename(used)} + profiles/valu_issue.json (static)"}
     except Exception:
         return None
 

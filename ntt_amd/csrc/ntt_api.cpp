@@ -605,8 +605,11 @@ std::vector<Step64> plan_steps(int log_len, size_t inner, size_t outer) {
         const int remaining = cur - stop;
         int q = 0;
         if (remaining >= TILE64_MIN_LOGR && is_pow2(inner)) {
+            // as few passes as possible; of those, the earlier (longer-stride) ones get the fewer rows: a tile whose rows lie
+            // megabytes apart is the slowest shape (3.2 ms against 2.3 ms per pass over 2^29 words for 512 rows)
             const int npass = (remaining + TILE64_MAX_LOGR - 1) / TILE64_MAX_LOGR;
-            q = (remaining + npass - 1) / npass;
+            q = remaining / npass;
+            if (remaining - q > TILE64_MAX_LOGR * (npass - 1)) q = remaining - TILE64_MAX_LOGR * (npass - 1);
             if (remaining - q > 0 && remaining - q < TILE64_MIN_LOGR) q = remaining - TILE64_MIN_LOGR;   // leave a tileable rest
             const uint64_t columns = ((uint64_t)1 << (cur - q)) * inner;
             if (q < TILE64_MIN_LOGR || q > TILE64_MAX_LOGR || columns % ((uint64_t)TILE64_N >> q) != 0) q = 0;

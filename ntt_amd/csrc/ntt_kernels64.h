@@ -29,10 +29,13 @@ namespace nttamd {
 constexpr int LOCAL64_LOG = 12;              // log2 of a k64_local chunk (4096 x 8 B = 32 KiB of LDS)
 constexpr int LOCAL64_N = 1 << LOCAL64_LOG;
 constexpr int LOCAL64_T = 256;               // threads of k64_local: 16 values each
-constexpr int TILE64_LOG = 13;               // log2 of a k64_tile tile (8192 x 8 B = 64 KiB of LDS)
+#ifndef NTT_TILE64_LOG
+#define NTT_TILE64_LOG 13                    // diagnostic builds may choose 12 (4096-word tiles, 256 threads)
+#endif
+constexpr int TILE64_LOG = NTT_TILE64_LOG;   // log2 of a k64_tile tile (8192 x 8 B = 64 KiB of LDS)
 constexpr int TILE64_N = 1 << TILE64_LOG;
-constexpr int TILE64_T = 512;                // threads of k64_tile: 16 values each
-constexpr int TILE64_MIN_LOGR = 5, TILE64_MAX_LOGR = 9;
+constexpr int TILE64_T = TILE64_N / 16;      // threads of k64_tile: 16 values each
+constexpr int TILE64_MIN_LOGR = 5, TILE64_MAX_LOGR = TILE64_LOG - 4;   // at least 16 adjacent columns (128 bytes) per row
 
 // Twiddles between the radix-16 rounds inside a tile or chunk: for block length Bk = 2^b (b = 5..12),
 // f[b][j*16 + pos] = w_Bk^(j * bitrev4(pos)), j < Bk/16 (i[b]: the inverse powers), in the field's twiddle form.
@@ -165,11 +168,29 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
     const int ql = ((q - 1) & 3) + 1;                           // levels of the last (smallest) round, 1..4
     V v[16];
 
-    auto boundary_exp = [&](int row) -> uint64_t {   // exponent of the pass twiddle for the frequency this row holds
-        const uint64_t k = bitrev64((uint64_t)row, q);
-        const uint64_t e = (jq * k * g.tw_stride) & g.tw_mask;
-        return INVERSE ? ((0 - e) & g.tw_mask) : e;
-    };
+    // Pass twiddles of the 16 rows 16*grp + i that a thread holds in the last forward / first inverse round: row r holds
+    // frequency k = bitrev_q(r) = bitrev4(i) << (q-4) | bitrev_{q-4}(grp), so the exponents jq * k * tw_stride are
+    // e0 + bitrev4(i) * de with two per-thread constants.  Only w^e0 and w^de are looked up (lanes hold different
+    // columns, so every lookup is a gather over the table); the sixteen twiddles w^(e0 + c*de) are then built by
+    // multiplication: three squarings of w^de and one multiply per twiddle.
+    W ptw[16];   // indexed by c = bitrev4(i)
+    {
+        const uint64_t k0 = bitrev64((uint64_t)grp, q - 4);
+        uint64_t e0 = (jq * k0 * g.tw_stride) & g.tw_mask, de = ((jq << (q - 4)) * g.tw_stride) & g.tw_mask;
+        if (INVERSE) { e0 = (0 - e0) & g.tw_mask; de = (0 - de) & g.tw_mask; }
+        const uint64_t lo_mask = ((uint64_t)1 << tw.t0) - 1;
+        auto lookup = [&](uint64_t e) -> W {
+            return f.twmul(f.tw_from_mem(tw.w1[e >> tw.t0]), f.tw_from_mem(tw.w0[e & lo_mask]));
+        };
+        const W s1 = lookup(de), s2 = f.twmul(s1, s1), s4 = f.twmul(s2, s2), s8 = f.twmul(s4, s4);
+        ptw[0] = lookup(e0);
+        static_for<1, 16>([&](auto C) {
+            constexpr int c = decltype(C)::value;
+            constexpr int low = c & -c;                       // lowest set bit: ptw[c] = ptw[c - low] * w^(low * de)
+            ptw[c] = f.twmul(ptw[c - low], low == 1 ? s1 : low == 2 ? s2 : low == 4 ? s4 : s8);
+        });
+    }
+    auto pass_twiddle = [&](auto I) -> W { return ptw[bitrev(decltype(I)::value, 4)]; };
 
     if (!INVERSE) {
         bool first = true;
@@ -178,16 +199,12 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
             const int blk = grp >> (b - 4), j = grp & (sub - 1);
             const int row0 = (blk << b) + j;
             if (first) {
+                uint64_t idx = origin + (uint64_t)row0 * step;
+                const uint64_t dstep = (uint64_t)sub * step;
 #pragma unroll
-                for (int m = 0; m < 16; ++m) {
-                    const uint64_t idx = origin + (uint64_t)(row0 + m * sub) * step;
-                    if (SRC_RAW) {
-                        const bool inside = idx < g.src_valid;
-                        const uint64_t raw = src[inside ? idx : 0];
-                        v[m] = f.from_raw(inside ? raw : 0);
-                    } else {
-                        v[m] = f.from_mem(data[idx]);
-                    }
+                for (int m = 0; m < 16; ++m, idx += dstep) {
+                    if (SRC_RAW) v[m] = idx < g.src_valid ? f.from_raw(src[idx]) : V(0);
+                    else v[m] = f.from_mem(data[idx]);
                 }
             } else {
 #pragma unroll
@@ -206,24 +223,17 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = lds[(((grp << 4) + i) << logW) + x];
         dif_blocks_rt<F>(ql, v, f, rF);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (grp << 4) + i;
-            const uint64_t e = boundary_exp(row);
-            V r = v[i];
-            if (e != 0) r = f.twiddled(r, twiddle_pow(tw, f, e));
-            data[origin + (uint64_t)row * step] = f.to_mem(r);
-        }
+        uint64_t idx = origin + (uint64_t)(grp << 4) * step;
+        static_for<0, 16>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            data[idx + (uint64_t)i * step] = f.to_mem(f.twiddled(v[i], pass_twiddle(I)));
+        });
     } else {
         // first round of the inverse = mirror of the last forward round
+        uint64_t idx = origin + (uint64_t)(grp << 4) * step;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (grp << 4) + i;
-            const uint64_t e = boundary_exp(row);
-            V r = f.from_mem(data[origin + (uint64_t)row * step]);
-            if (e != 0) r = f.twiddled(r, twiddle_pow(tw, f, e));
-            v[i] = r;
-        }
+        for (int i = 0; i < 16; ++i, idx += step) v[i] = f.from_mem(data[idx]);
+        static_for<0, 16>([&](auto I) { constexpr int i = decltype(I)::value; v[i] = f.twiddled(v[i], pass_twiddle(I)); });
         dit_blocks_rt<F>(ql, v, f, rI);
 #pragma unroll
         for (int i = 0; i < 16; ++i) lds[(((grp << 4) + i) << logW) + x] = v[i];
@@ -244,13 +254,14 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
                 for (int m = 0; m < 16; ++m) lds[((row0 + m * sub) << logW) + x] = v[m];
                 __syncthreads();
             } else {
+                uint64_t o = origin + (uint64_t)row0 * step;
+                const uint64_t dstep = (uint64_t)sub * step;
 #pragma unroll
-                for (int m = 0; m < 16; ++m) {
-                    const uint64_t idx = origin + (uint64_t)(row0 + m * sub) * step;
+                for (int m = 0; m < 16; ++m, o += dstep) {
                     if (FINAL) {
-                        if (idx < n_out) out[idx] = f.canon(f.twiddled(v[m], scale));
+                        if (o < n_out) out[o] = f.canon(f.twiddled(v[m], scale));
                     } else {
-                        data[idx] = f.to_mem(v[m]);
+                        data[o] = f.to_mem(v[m]);
                     }
                 }
             }

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=28)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--direct-only", action="store_true")
+    ap.add_argument("--warm", type=int, default=4, help="untimed products before the timed ones")
     args = ap.parse_args()
     n = 1 << args.log_n
     lib = load_product_library(); lib.init(0)
@@ -50,7 +51,9 @@ def main():
 
     def direct():
         lib.check(lib.lib.ntt64_poly_multiply_device(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, P, ws.data_ptr(), ws_bytes, st))
-    direct(); torch.cuda.synchronize()
+    for _ in range(args.warm):     # the GPU's clocks dip during the first tens of milliseconds of a sustained load
+        direct()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.reps):
         direct()
