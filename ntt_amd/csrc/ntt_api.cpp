@@ -103,6 +103,7 @@ struct Plan {
     DevBuf tables;
     const uint32_t *twF = nullptr, *twI = nullptr, *ow = nullptr, *T1 = nullptr, *T3 = nullptr;
     CoreTables core{};
+    RoundTables32 rt{};
 };
 
 // 64-bit field: constants of both arithmetic flavours, the two-level twiddle tables for the root of order
@@ -261,6 +262,8 @@ int get_plan(Device* dev, uint32_t p, int logL, Plan** out) {
     size_t o_twF = stage(img, h.twF), o_twI = stage(img, h.twI), o_ow = stage(img, h.ow);
     size_t o_1F = stage(img, h.tw1F), o_2F = stage(img, h.tw2F), o_1I = stage(img, h.tw1I), o_2I = stage(img, h.tw2I);
     size_t o_T1 = stage(img, h.T1), o_T3 = stage(img, h.T3);
+    size_t o_rtF[13] = {0}, o_rtI[13] = {0};
+    for (int b = 0; b < 13; ++b) { o_rtF[b] = stage(img, h.rtF[b]); o_rtI[b] = stage(img, h.rtI[b]); }
     if (img.empty()) img.push_back(0);
     int rc = pl->tables.ensure(img.size() * sizeof(uint32_t));
     if (rc != NTT_OK) return rc;
@@ -269,6 +272,10 @@ int get_plan(Device* dev, uint32_t p, int logL, Plan** out) {
     pl->twF = base + o_twF; pl->twI = base + o_twI; pl->ow = base + o_ow;
     pl->core.tw1F = base + o_1F; pl->core.tw2F = base + o_2F; pl->core.tw1I = base + o_1I; pl->core.tw2I = base + o_2I;
     pl->T1 = base + o_T1; pl->T3 = base + o_T3;
+    for (int b = 0; b < 13; ++b) {
+        pl->rt.f[b] = h.rtF[b].empty() ? nullptr : base + o_rtF[b];
+        pl->rt.i[b] = h.rtI[b].empty() ? nullptr : base + o_rtI[b];
+    }
     // the big host vectors are no longer needed
     std::vector<uint32_t>().swap(h.T1); std::vector<uint32_t>().swap(h.T3);
     *out = pl.get();
@@ -309,6 +316,12 @@ int launch_product(const Plan& pl, const TIn* a, const TIn* b, TOut* out, int n,
     const int n_out = 2 * n - 1;
     switch (pl.h.kind) {
         case PLAN_SMALL:
+            if (pl.h.small16) {
+                const unsigned per_wg = 1u << (12 - pl.h.logL);   // products per workgroup
+                NTT_LAUNCH_P("k_small16", (k_small16<LZ, TIn, TOut>), dim3((unsigned)((batch + per_wg - 1) / per_wg)), dim3(CORE_T), st,
+                             a, b, out, sa, sb, so, n, n_out, pl.h.logL, batch, pl.h.scale_m, pl.h.fc, pl.rt);
+                break;
+            }
             NTT_LAUNCH_P("k_small", (k_small<LZ, TIn, TOut>), dim3((unsigned)batch), dim3(256), st, a, b, out, sa, sb, so, n, n_out,
                        pl.h.logL, pl.twF, pl.twI, pl.h.scale_m, pl.h.fc);
             break;
@@ -1639,7 +1652,7 @@ int ntt_describe_plan(int n, uint64_t p, char* buf, size_t buf_len) {
     const int logL = transform_log2(n);
     std::string s, why;
     const Route route = choose_route(p, (size_t)n, &why);
-    const char* pipe = logL <= 12 ? "k_small" : logL == 13 ? "k_fused8192" : "k_fwd_strided,k_core_mul,k_inv_strided";
+    const char* pipe = logL <= 12 ? ((logL >= 5 && p < (1ull << 31) && (p - 1) % 64 == 0) ? "k_small16" : "k_small") : logL == 13 ? "k_fused8192" : "k_fwd_strided,k_core_mul,k_inv_strided";
     if (route == ROUTE_DIRECT32) s = pipe;
     else if (route == ROUTE_CRT) s = std::string("4x(") + pipe + "),k_crt_merge";
     else if (route == ROUTE_FIELD64) s = "k64_tile,k64_local,k64_strided,k64_load,k64_pointwise,k64_finalize";

@@ -452,6 +452,133 @@ __global__ void __launch_bounds__(256) k_small(const TIn* A, const TIn* Bp, TOut
 }
 
 // ---------------------------------------------------------------------------
+// k_small16: whole products for L = 2^logL, 32 <= L <= 4096, when 64 | p-1.  A workgroup of 256 threads holds
+// 4096 / L products in LDS (4096 values of A and of B) and runs radix-16 register rounds with one LDS exchange
+// between rounds, like the 4096-point core, for every length:
+//   round over blocks of 2^b values (b = logL, logL-4, ... > 4): thread t takes values e0 + k * 2^(b-4), k < 16
+//   last round (blocks of 2^ql <= 16 values): values 16 t + i.
+// The pointwise product and the first inverse round stay in the registers of the last forward round.
+// rt.f[b][j*16 + pos] = Montgomery form of w_{2^b}^(j * bitrev4(pos)), rt.i[b] the inverse powers.
+// ---------------------------------------------------------------------------
+struct RoundTables32 {
+    const uint32_t* f[13];
+    const uint32_t* i[13];
+};
+
+// 2^Q-point transforms on the 16 >> Q consecutive blocks of a 16-entry array
+template <int Q, bool LZ>
+__device__ __forceinline__ void dif_blocks32(uint32_t (&x)[16], const Field<LZ>& f, const FieldConsts& fc) {
+    static_for<0, (16 >> Q)>([&](auto Bk) {
+        constexpr int off = decltype(Bk)::value << Q;
+        uint32_t y[1 << Q];
+        static_for<0, (1 << Q)>([&](auto I) { y[decltype(I)::value] = x[off + decltype(I)::value]; });
+        dif_reg<Q, LZ>(y, f, fc.rootF, fc.rootFn);
+        static_for<0, (1 << Q)>([&](auto I) { x[off + decltype(I)::value] = y[decltype(I)::value]; });
+    });
+}
+template <int Q, bool LZ>
+__device__ __forceinline__ void dit_blocks32(uint32_t (&x)[16], const Field<LZ>& f, const FieldConsts& fc) {
+    static_for<0, (16 >> Q)>([&](auto Bk) {
+        constexpr int off = decltype(Bk)::value << Q;
+        uint32_t y[1 << Q];
+        static_for<0, (1 << Q)>([&](auto I) { y[decltype(I)::value] = x[off + decltype(I)::value]; });
+        dit_reg<Q, LZ, true>(y, f, fc.rootI);
+        static_for<0, (1 << Q)>([&](auto I) { x[off + decltype(I)::value] = y[decltype(I)::value]; });
+    });
+}
+
+__device__ __forceinline__ int small_slot(int e) { return core_slot(e >> 8, (e >> 4) & 15, e & 15); }
+
+template <bool LZ, typename TIn, typename TOut>
+__global__ void __launch_bounds__(CORE_T) k_small16(const TIn* A, const TIn* Bp, TOut* out, size_t a_stride, size_t b_stride,
+                                                    size_t out_stride, int n, int n_out, int logL, size_t batch,
+                                                    uint32_t scale_m, FieldConsts fc, RoundTables32 rt) {
+    __shared__ uint32_t la[CORE_N];
+    __shared__ uint32_t lb[CORE_N];
+    const Field<LZ> f(fc);
+    const int t = threadIdx.x;
+    const int ql = ((logL - 1) & 3) + 1;
+    const size_t first = (size_t)blockIdx.x << (12 - logL);     // first product of this workgroup
+    uint32_t a[16], b[16];
+    // operands -> LDS, zero padded (values beyond n, products beyond the batch)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = t + CORE_T * i;
+        const size_t prod = first + (size_t)(e >> logL);
+        const int idx = e & ((1 << logL) - 1);
+        const bool inside = prod < batch && idx < n;
+        const int s = small_slot(e);
+        la[s] = inside ? load_coeff<LZ>(A + prod * a_stride, (size_t)idx, f, fc) : 0u;
+        lb[s] = inside ? load_coeff<LZ>(Bp + prod * b_stride, (size_t)idx, f, fc) : 0u;
+    }
+    __syncthreads();
+    // forward rounds
+    for (int bl = logL; bl > 4; bl -= 4) {
+        const int sub = 1 << (bl - 4);
+        const int blk = t >> (bl - 4), j = t & (sub - 1);
+        const int e0 = (blk << bl) + j;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int s = small_slot(e0 + k * sub); a[k] = la[s]; b[k] = lb[s]; }
+        dif_reg<4, LZ, false, true>(a, f, fc.rootF, fc.rootFn);
+        dif_reg<4, LZ, false, true>(b, f, fc.rootF, fc.rootFn);
+        uint32_t tw[16];
+        load_tw16(tw, rt.f[bl], j);
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) {
+            if (pos) { a[pos] = f.mulw(a[pos], tw[pos]); b[pos] = f.mulw(b[pos], tw[pos]); }
+            const int s = small_slot(e0 + pos * sub);
+            la[s] = a[pos]; lb[s] = b[pos];
+        }
+        __syncthreads();
+    }
+    // last forward round, pointwise product, first inverse round: all on values 16 t + i
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int s = small_slot((t << 4) + i); a[i] = la[s]; b[i] = lb[s]; }
+    switch (ql) {
+        case 1: dif_blocks32<1, LZ>(a, f, fc); dif_blocks32<1, LZ>(b, f, fc); break;
+        case 2: dif_blocks32<2, LZ>(a, f, fc); dif_blocks32<2, LZ>(b, f, fc); break;
+        case 3: dif_blocks32<3, LZ>(a, f, fc); dif_blocks32<3, LZ>(b, f, fc); break;
+        default: dif_blocks32<4, LZ>(a, f, fc); dif_blocks32<4, LZ>(b, f, fc); break;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = f.mulpw(a[i], b[i]);
+    switch (ql) {
+        case 1: dit_blocks32<1, LZ>(a, f, fc); break;
+        case 2: dit_blocks32<2, LZ>(a, f, fc); break;
+        case 3: dit_blocks32<3, LZ>(a, f, fc); break;
+        default: dit_blocks32<4, LZ>(a, f, fc); break;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) la[small_slot((t << 4) + i)] = a[i];
+    // remaining inverse rounds
+    for (int bl = ql + 4; bl <= logL; bl += 4) {
+        __syncthreads();
+        const int sub = 1 << (bl - 4);
+        const int blk = t >> (bl - 4), j = t & (sub - 1);
+        const int e0 = (blk << bl) + j;
+        uint32_t tw[16];
+        load_tw16(tw, rt.i[bl], j);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t v = la[small_slot(e0 + k * sub)];
+            a[k] = k ? f.mulw(v, tw[k]) : (LZ ? csub(v, f.B) : v);
+        }
+        dit_reg<4, LZ, true>(a, f, fc.rootI);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) la[small_slot(e0 + k * sub)] = a[k];
+    }
+    __syncthreads();
+    // scale by L^-1 (and the factor the pointwise product left), canonical, first 2n-1 coefficients of every product
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = t + CORE_T * i;
+        const size_t prod = first + (size_t)(e >> logL);
+        const int idx = e & ((1 << logL) - 1);
+        if (prod < batch && idx < n_out) out[prod * out_stride + idx] = (TOut)f.canon_fwd(f.mulw(la[small_slot(e)], scale_m));
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_crt_merge: 128-bit CRT recombination, one thread per coefficient.
 //   S = sum_i M_i * ((r_i * M_i^-1) mod p_i);  S mod M;  then mod p.
 // Same value as the reference loop (main_naive.cc:216-223, main_mpi_CRT.cc:512-522): the sum

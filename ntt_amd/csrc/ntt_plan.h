@@ -103,6 +103,8 @@ struct PlanHost {
     FieldConsts fc{};
     uint32_t scale_m = 0;             // Montgomery form of L^-1 * R
     std::vector<uint32_t> twF, twI;   // small: wL^(+-e), e < L/2
+    bool small16 = false;             // small: the radix-16 kernel applies (L >= 32 and 64 | p-1)
+    std::vector<uint32_t> rtF[13], rtI[13];   // small16: round tables for blocks of 2^b, b = 5..logL
     std::vector<uint32_t> tw1F, tw2F, tw1I, tw2I;  // core tables
     std::vector<uint32_t> ow;         // fused8192: [w8192^j | w8192^-j], j < 4096
     std::vector<uint32_t> T1, T3;     // multipass strided twiddles, L entries each
@@ -161,6 +163,25 @@ inline bool build_plan_host(uint32_t p, int logL, PlanHost& h, std::string* err)
         for (uint64_t e = 0; e < L / 2; ++e) {
             h.twF[e] = h_mont(a, p); h.twI[e] = h_mont(b, p);
             a = h_mulmod(a, wL, p); b = h_mulmod(b, wLi, p);
+        }
+        h.small16 = logL >= 5 && (p - 1) % 64 == 0;
+#ifdef NTT_NO_SMALL16   // diagnostic builds: the radix-2 kernel for every short product
+        h.small16 = false;
+#endif
+        if (h.small16) {
+            for (int bl = logL; bl > 4; bl -= 4) {   // the rounds of k_small16
+                const uint64_t wB = h_powmod(wL, 1ull << (logL - bl), p), wBi = h_powmod(wB, p - 2, p);
+                const size_t sub = (size_t)1 << (bl - 4);
+                h.rtF[bl].resize(sub << 4); h.rtI[bl].resize(sub << 4);
+                for (int pos = 0; pos < 16; ++pos) {
+                    const uint64_t sF = h_powmod(wB, (uint64_t)bitrev(pos, 4), p), sI = h_powmod(wBi, (uint64_t)bitrev(pos, 4), p);
+                    uint64_t vF = 1, vI = 1;
+                    for (size_t j = 0; j < sub; ++j) {
+                        h.rtF[bl][(j << 4) + pos] = h_mont(vF, p); h.rtI[bl][(j << 4) + pos] = h_mont(vI, p);
+                        vF = h_mulmod(vF, sF, p); vI = h_mulmod(vI, sI, p);
+                    }
+                }
+            }
         }
     } else if (logL == 13) {
         h.kind = PLAN_FUSED8192;

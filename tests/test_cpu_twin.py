@@ -422,3 +422,18 @@ def test_batches_sharded_over_several_devices_inside_the_library(twin, tmp_path)
     r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, NTT_TWIN_DEVICES="3"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "RESULT True True" in r.stdout, r.stdout[-500:]
+
+
+def test_short_products_several_per_workgroup(twin, oracle):
+    """Transform lengths 32..4096 run 4096 / L products per workgroup (k_small16): batches that do not fill the last
+    workgroup, every length class, both lazy and non-lazy primes; lengths below 32 keep the radix-2 kernel."""
+    rng = np.random.default_rng(16)
+    for p in (998244353, 1224736769, 7340033):
+        for n, batch in ((16, 300), (17, 5), (31, 129), (100, 33), (256, 17), (500, 9), (1024, 5), (2048, 3), (2048, 1), (8, 1000), (3, 7)):
+            a = rng.integers(0, p, (batch, n), dtype=np.uint32); b = rng.integers(0, p, (batch, n), dtype=np.uint32)
+            a[0] = p - 1; b[0] = p - 1
+            got = twin.multiply_batched(a, b, p, 1)
+            for r in sorted({0, 1 % batch, batch // 2, batch - 1}):
+                want = oracle.ntt_multiply(a[r], b[r], p) if n & (n - 1) == 0 else oracle.schoolbook_u64(a[r], b[r], p)
+                assert np.array_equal(got[r].astype(np.uint64), want), (p, n, batch, r)
+    assert twin.describe_plan(1000, 998244353) == "k_small16" and twin.describe_plan(8, 998244353) == "k_small"
