@@ -645,50 +645,88 @@ struct TileExtra {           // fusions of a product's first and last pass
     const uint64_t* other = nullptr;                                      // inverse local pass: pointwise product first
 };
 
+// Where the passes of one transform live and which twiddles join them: the middle axis of [outer][2^log_len][inner].
+// col_bits > 0: the array is a slab of a four-step matrix -- its `inner` columns are columns col0.. of 2^col_bits, and
+// the passes are the first log_len levels of the transform of the whole matrix (length 2^(log_len + col_bits)), so that
+// the twiddles between the two axes of the matrix come with them.
+struct Axis64 {
+    int log_len = 0;
+    size_t inner = 1, outer = 1;
+    int col_bits = 0;
+    uint64_t col0 = 0;
+};
+
+int log2_exact(uint64_t x) {
+    int l = 0;
+    while (((uint64_t)1 << l) < x) ++l;
+    return l;
+}
+
 template <class F>
-int run_step(const Plan64& pl, uint64_t* d, const Step64& s, int log_len, size_t inner, size_t outer, bool inverse,
-             const TileExtra& ex, hipStream_t st) {
+int launch_pass(const Plan64& pl, uint64_t* d, bool tile, const Pass64& g, bool inverse, const TileExtra& ex, hipStream_t st) {
     const typename F::Consts& fc = consts_of<F>(pl);
-    if (s.kind == Step64::TILE || s.kind == Step64::REG) {
-        Pass64 g{};
-        g.cq = (uint64_t)1 << (s.cur - s.q);
-        g.inner = inner;
-        g.n_threads = ((uint64_t)outer << (log_len - s.cur)) * g.cq * inner;
-        g.tw_stride = (uint64_t)1 << (pl.log_root - s.cur);
-        g.tw_mask = ((uint64_t)1 << pl.log_root) - 1;
-        g.q = s.q;
-        g.src_valid = ex.src_valid;
-        if (s.kind == Step64::REG) {
-            if (g.n_threads / 256 >= (1ull << 31)) return fail(NTT_ERR_ARG, "transform too large for one launch");
-            const unsigned grid = (unsigned)((g.n_threads + 255) / 256);
+    if (!tile) {
+        const uint64_t threads = g.n_blocks * g.columns;
+        if (threads / 256 >= (1ull << 31)) return fail(NTT_ERR_ARG, "transform too large for one launch");
+        const unsigned grid = (unsigned)((threads + 255) / 256);
 #define NTT_REG_CASE(Q)                                                                                              \
     if (inverse) NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, true>), dim3(grid), dim3(256), st, d, g, fc, pl.tw);  \
     else NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, false>), dim3(grid), dim3(256), st, d, g, fc, pl.tw)
-            switch (s.q) {
-                case 1: NTT_REG_CASE(1); break;
-                case 2: NTT_REG_CASE(2); break;
-                case 3: NTT_REG_CASE(3); break;
-                default: NTT_REG_CASE(4); break;
-            }
-#undef NTT_REG_CASE
-        } else {
-            int li = 0;
-            while (((uint64_t)1 << li) < inner) ++li;
-            g.log_inner = li;
-            g.tiles_per_block = g.cq * inner / ((uint64_t)TILE64_N >> s.q);
-            const uint64_t tiles = ((uint64_t)outer << (log_len - s.cur)) * g.tiles_per_block;
-            if (tiles >= (1ull << 31)) return fail(NTT_ERR_ARG, "transform too large for one launch");
-            const unsigned grid = (unsigned)tiles;
-            const typename F::W scale = scale_arg<F>(ex.scale_word);
-            if (!inverse) {
-                if (ex.src) NTT_LAUNCH_P("k64_tile", (k64_tile<F, false, true, false>), dim3(grid), dim3(TILE64_T), st, d, ex.src, (uint64_t*)nullptr, (uint64_t)0, scale, g, fc, pl.tw, pl.rt);
-                else NTT_LAUNCH_P("k64_tile", (k64_tile<F, false, false, false>), dim3(grid), dim3(TILE64_T), st, d, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, scale, g, fc, pl.tw, pl.rt);
-            } else {
-                if (ex.out) NTT_LAUNCH_P("k64_tile", (k64_tile<F, true, false, true>), dim3(grid), dim3(TILE64_T), st, d, (const uint64_t*)nullptr, ex.out, ex.n_out, scale, g, fc, pl.tw, pl.rt);
-                else NTT_LAUNCH_P("k64_tile", (k64_tile<F, true, false, false>), dim3(grid), dim3(TILE64_T), st, d, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, scale, g, fc, pl.tw, pl.rt);
-            }
+        switch (g.q) {
+            case 1: NTT_REG_CASE(1); break;
+            case 2: NTT_REG_CASE(2); break;
+            case 3: NTT_REG_CASE(3); break;
+            default: NTT_REG_CASE(4); break;
         }
-    } else if (s.kind == Step64::LOCAL) {
+#undef NTT_REG_CASE
+    } else {
+        const uint64_t tiles = g.n_blocks * g.tiles_per_block;
+        if (tiles >= (1ull << 31)) return fail(NTT_ERR_ARG, "transform too large for one launch");
+        const unsigned grid = (unsigned)tiles;
+        const typename F::W scale = scale_arg<F>(ex.scale_word);
+        if (!inverse) {
+            if (ex.src) NTT_LAUNCH_P("k64_tile", (k64_tile<F, false, true, false>), dim3(grid), dim3(TILE64_T), st, d, ex.src, (uint64_t*)nullptr, (uint64_t)0, scale, g, fc, pl.tw, pl.rt);
+            else NTT_LAUNCH_P("k64_tile", (k64_tile<F, false, false, false>), dim3(grid), dim3(TILE64_T), st, d, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, scale, g, fc, pl.tw, pl.rt);
+        } else {
+            if (ex.out) NTT_LAUNCH_P("k64_tile", (k64_tile<F, true, false, true>), dim3(grid), dim3(TILE64_T), st, d, (const uint64_t*)nullptr, ex.out, ex.n_out, scale, g, fc, pl.tw, pl.rt);
+            else NTT_LAUNCH_P("k64_tile", (k64_tile<F, true, false, false>), dim3(grid), dim3(TILE64_T), st, d, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, scale, g, fc, pl.tw, pl.rt);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+
+template <class F>
+int run_step(const Plan64& pl, uint64_t* d, const Step64& s, const Axis64& ax, bool inverse, const TileExtra& ex, hipStream_t st) {
+    const typename F::Consts& fc = consts_of<F>(pl);
+    const int log_len = ax.log_len;
+    const size_t inner = ax.inner, outer = ax.outer;
+    if (s.kind == Step64::TILE || s.kind == Step64::REG) {
+        Pass64 g{};
+        g.columns = ((uint64_t)1 << (s.cur - s.q)) * inner;
+        g.step = g.columns;
+        g.block_stride = g.columns << s.q;
+        g.n_blocks = (uint64_t)outer << (log_len - s.cur);
+        g.tw_mask = ((uint64_t)1 << pl.log_root) - 1;
+        g.q = s.q;
+        g.src_valid = ex.src_valid;
+        g.hi_shift = 63;
+        g.lo_mask = ~(uint64_t)0;
+        if (ax.col_bits == 0) {           // plain transform: the twiddle index is the column's position in the block, x / inner
+            if (is_pow2(inner)) g.lo_shift = log2_exact(inner); else g.inner_div = inner;
+            g.tw_stride = (uint64_t)1 << (pl.log_root - s.cur);
+        } else {                           // slab of a matrix: jq = (x / inner) * 2^col_bits + col0 + x % inner
+            const int li = log2_exact(inner);
+            g.lo_mask = inner - 1;
+            g.hi_shift = li;
+            g.hi_lshift = ax.col_bits;
+            g.jq_off = ax.col0;
+            g.tw_stride = (uint64_t)1 << (pl.log_root - s.cur - ax.col_bits);
+        }
+        if (s.kind == Step64::TILE) g.tiles_per_block = g.columns / ((uint64_t)TILE64_N >> s.q);
+        return launch_pass<F>(pl, d, s.kind == Step64::TILE, g, inverse, ex, st);
+    }
+    if (s.kind == Step64::LOCAL) {
         const uint64_t n_chunks = ((uint64_t)outer << log_len) >> LOCAL64_LOG;
         const unsigned grid = (unsigned)(n_chunks < (1u << 20) ? n_chunks : (1u << 20));
         const typename F::W scale = scale_arg<F>(ex.scale_word);
@@ -705,24 +743,72 @@ int run_step(const Plan64& pl, uint64_t* d, const Step64& s, int log_len, size_t
     return NTT_OK;
 }
 
-// in-place transform along the middle axis of [outer][2^log_len][inner]
+// in-place transform along the axis
 template <class F>
-int transform64_f(const Plan64& pl, uint64_t* d, int log_len, size_t inner, size_t outer, bool inverse, hipStream_t st) {
-    const std::vector<Step64> steps = plan_steps(log_len, inner, outer);
+int transform64_f(const Plan64& pl, uint64_t* d, const Axis64& ax, bool inverse, hipStream_t st) {
+    const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer);
     const TileExtra none;
     int rc;
     if (!inverse) {
-        for (const Step64& s : steps) if ((rc = run_step<F>(pl, d, s, log_len, inner, outer, false, none, st)) != NTT_OK) return rc;
+        for (const Step64& s : steps) if ((rc = run_step<F>(pl, d, s, ax, false, none, st)) != NTT_OK) return rc;
     } else {
-        for (size_t i = steps.size(); i-- > 0;) if ((rc = run_step<F>(pl, d, steps[i], log_len, inner, outer, true, none, st)) != NTT_OK) return rc;
+        for (size_t i = steps.size(); i-- > 0;) if ((rc = run_step<F>(pl, d, steps[i], ax, true, none, st)) != NTT_OK) return rc;
     }
     return NTT_OK;
 }
 
+int transform64_axis(const Plan64& pl, uint64_t* d, const Axis64& ax, bool inverse, hipStream_t st) {
+    if (ax.log_len + ax.col_bits > pl.log_root) return fail(NTT_ERR_ARG, "transform longer than the plan's root order");
+    if (ax.log_len == 0 || ax.outer == 0 || ax.inner == 0) return NTT_OK;
+    return pl.fp ? transform64_f<FieldD>(pl, d, ax, inverse, st) : transform64_f<Field64>(pl, d, ax, inverse, st);
+}
+
 int transform64(const Plan64& pl, uint64_t* d, int log_len, size_t inner, size_t outer, bool inverse, hipStream_t st) {
-    if (log_len > pl.log_root) return fail(NTT_ERR_ARG, "transform longer than the plan's root order");
-    if (log_len == 0 || outer == 0 || inner == 0) return NTT_OK;
-    return pl.fp ? transform64_f<FieldD>(pl, d, log_len, inner, outer, inverse, st) : transform64_f<Field64>(pl, d, log_len, inner, outer, inverse, st);
+    Axis64 ax;
+    ax.log_len = log_len; ax.inner = inner; ax.outer = outer;
+    return transform64_axis(pl, d, ax, inverse, st);
+}
+
+// The column axis of a four-step matrix in the layout an all-to-all of column slabs leaves: the axis index
+// c = part * Cl + l (part < 2^log_parts, l < Cl = 2^(log_cols - log_parts)) of row r lives at
+// part * part_stride + r * Cl + l, r < rows.  Forward: one register pass over the parts (their twiddles depend on l
+// only), then plain transforms of length Cl on every (part, row); inverse: the mirror.
+int transform64_split(const Plan64& pl, uint64_t* d, int log_cols, int log_parts, uint64_t part_stride, uint64_t rows, bool inverse,
+                      hipStream_t st) {
+    if (log_parts < 0 || log_parts > 4 || log_parts > log_cols) return fail(NTT_ERR_ARG, "split layout supports 1 to 16 parts");
+    if (log_cols > pl.log_root) return fail(NTT_ERR_ARG, "transform longer than the plan's root order");
+    if (rows == 0) return NTT_OK;
+    const int log_cl = log_cols - log_parts;
+    const uint64_t cl = (uint64_t)1 << log_cl;
+    auto parts_pass = [&]() -> int {
+        if (log_parts == 0) return NTT_OK;
+        Pass64 g{};
+        g.columns = rows * cl;
+        g.step = part_stride;
+        g.block_stride = 0;
+        g.n_blocks = 1;
+        g.q = log_parts;
+        g.hi_shift = 63;
+        g.lo_mask = cl - 1;            // jq = l: the position inside the part
+        g.tw_stride = (uint64_t)1 << (pl.log_root - log_cols);
+        g.tw_mask = ((uint64_t)1 << pl.log_root) - 1;
+        const TileExtra none;
+        return pl.fp ? launch_pass<FieldD>(pl, d, false, g, inverse, none, st) : launch_pass<Field64>(pl, d, false, g, inverse, none, st);
+    };
+    auto rows_of_parts = [&]() -> int {
+        for (uint64_t part = 0; part < ((uint64_t)1 << log_parts); ++part) {
+            int rc = transform64(pl, d + part * part_stride, log_cl, 1, rows, inverse, st);
+            if (rc != NTT_OK) return rc;
+        }
+        return NTT_OK;
+    };
+    int rc;
+    if (!inverse) {
+        if ((rc = parts_pass()) != NTT_OK) return rc;
+        return rows_of_parts();
+    }
+    if ((rc = rows_of_parts()) != NTT_OK) return rc;
+    return parts_pass();
 }
 
 // element-wise kernels, by field
@@ -762,15 +848,17 @@ int product64_row(const Plan64& pl, const uint64_t* a, const uint64_t* b, uint64
     const uint64_t Linv = h_powmod((uint64_t)L % p, p - 2, p);
     const uint64_t scale = h_mulmod(Linv, pointwise_compensation(pl), p);
     const std::vector<Step64> steps = plan_steps(logL, 1, 1);
+    Axis64 ax;
+    ax.log_len = logL;
     int rc;
     const bool fused = steps.size() >= 2 && steps.front().kind == Step64::TILE && steps.back().kind == Step64::LOCAL;
     if (!fused) {
         load64(pl, a, 0, n, wa, L, 1, st);
         load64(pl, b, 0, n, wb, L, 1, st);
-        if ((rc = transform64_f<F>(pl, wa, logL, 1, 1, false, st)) != NTT_OK) return rc;
-        if ((rc = transform64_f<F>(pl, wb, logL, 1, 1, false, st)) != NTT_OK) return rc;
+        if ((rc = transform64_f<F>(pl, wa, ax, false, st)) != NTT_OK) return rc;
+        if ((rc = transform64_f<F>(pl, wb, ax, false, st)) != NTT_OK) return rc;
         pointwise64(pl, wa, wb, L, st);
-        if ((rc = transform64_f<F>(pl, wa, logL, 1, 1, true, st)) != NTT_OK) return rc;
+        if ((rc = transform64_f<F>(pl, wa, ax, true, st)) != NTT_OK) return rc;
         finalize64(pl, wa, L, out, 0, 2 * n - 1, 1, scale, st);
         HIP_TRY(hipGetLastError());
         return NTT_OK;
@@ -782,13 +870,13 @@ int product64_row(const Plan64& pl, const uint64_t* a, const uint64_t* b, uint64
         first.src = side ? b : a;
         first.src_valid = n;
         for (size_t i = 0; i < steps.size(); ++i)
-            if ((rc = run_step<F>(pl, w, steps[i], logL, 1, 1, false, i == 0 ? first : none, st)) != NTT_OK) return rc;
+            if ((rc = run_step<F>(pl, w, steps[i], ax, false, i == 0 ? first : none, st)) != NTT_OK) return rc;
     }
     for (size_t i = steps.size(); i-- > 0;) {
         TileExtra ex;
         if (i + 1 == steps.size()) ex.other = wb;
         if (i == 0) { ex.out = out; ex.n_out = 2 * n - 1; ex.scale_word = tw_word(pl, scale); }
-        if ((rc = run_step<F>(pl, wa, steps[i], logL, 1, 1, true, ex, st)) != NTT_OK) return rc;
+        if ((rc = run_step<F>(pl, wa, steps[i], ax, true, ex, st)) != NTT_OK) return rc;
     }
     return NTT_OK;
 }

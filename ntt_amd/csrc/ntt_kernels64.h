@@ -44,20 +44,31 @@ struct RoundTables64 {
     const uint64_t* i[14];
 };
 
-// one pass over blocks of length Lb = cq << q along the axis: a "column" is (jq < cq, c < inner); its 2^q rows are
-// cq*inner elements apart; afterwards (forward) / beforehand (inverse) row k is multiplied by w_Lb^(+-jq * bitrev_q(k)).
+// One pass of q levels over blocks of 2^q rows.  Memory: block b starts at b * block_stride; its rows are `step` elements
+// apart; a row holds `columns` adjacent "fused columns" x.  Afterwards (forward) / beforehand (inverse) row k of column
+// x is multiplied by w^(+-jq(x) * bitrev_q(k) * tw_stride), w the plan's root, where the twiddle index of a column is
+//   jq(x) = ((x >> hi_shift) << hi_lshift) + (lo(x) & lo_mask) + jq_off,   lo(x) = x / inner_div or x >> lo_shift.
+// A plain transform along the middle axis of [outer][len][inner] has lo = x / inner and nothing else; the passes of a
+// four-step slab (columns col0.. of a wider matrix) and of the split layout an all-to-all leaves use the other terms.
 struct Pass64 {
-    uint64_t cq;        // columns per block
-    uint64_t inner;     // contiguous inner extent S
-    uint64_t n_threads; // k64_strided: blocks * cq * inner
-    uint64_t tw_stride; // (table root order) / Lb : exponent scale to the table's root
-    uint64_t tw_mask;   // table root order - 1
-    // k64_tile only
-    int q;              // log2 rows
-    int log_inner;      // inner is a power of two there
-    uint64_t tiles_per_block;   // cq*inner / W
-    uint64_t src_valid; // first pass of a product reading caller data: elements of the source beyond this index are zero
+    uint64_t columns;       // fused columns per block row
+    uint64_t step;          // elements between rows
+    uint64_t block_stride;  // elements between blocks
+    uint64_t n_blocks;
+    uint64_t inner_div;     // 0: lo(x) = x >> lo_shift; else lo(x) = x / inner_div (extents that are not powers of two)
+    int lo_shift, hi_shift, hi_lshift;
+    uint64_t lo_mask, jq_off;
+    uint64_t tw_stride;     // exponent scale to the table's root
+    uint64_t tw_mask;       // table root order - 1
+    int q;                  // log2 rows
+    uint64_t tiles_per_block;   // k64_tile: columns / W
+    uint64_t src_valid;     // first pass of a product reading caller data: elements of the source beyond this index are zero
 };
+
+NTT_HD uint64_t pass_jq(const Pass64& g, uint64_t x) {
+    const uint64_t lo = g.inner_div ? x / g.inner_div : x >> g.lo_shift;
+    return ((x >> g.hi_shift) << g.hi_lshift) + (lo & g.lo_mask) + g.jq_off;
+}
 
 // ---------------------------------------------------------------------------
 // register transforms on 2^Q consecutive entries of a 16-entry array, entries OFF .. OFF + 2^Q - 1
@@ -161,10 +172,10 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
     const int x = t & ((1 << logW) - 1), grp = t >> logW;
     const uint64_t tile = blockIdx.x;
     const uint64_t blk_g = tile / g.tiles_per_block, xt = tile % g.tiles_per_block;
-    const uint64_t step = g.cq * g.inner;                       // elements between rows
-    const uint64_t col = (xt << logW) + (uint64_t)x;            // fused column (jq, c) inside the block
-    const uint64_t origin = (blk_g << q) * step + col;          // element offset of row 0 of this column
-    const uint64_t jq = col >> g.log_inner;
+    const uint64_t step = g.step;                               // elements between rows
+    const uint64_t col = (xt << logW) + (uint64_t)x;            // fused column inside the block
+    const uint64_t origin = blk_g * g.block_stride + col;       // element offset of row 0 of this column
+    const uint64_t jq = pass_jq(g, col);
     const int ql = ((q - 1) & 3) + 1;                           // levels of the last (smallest) round, 1..4
     V v[16];
 
@@ -371,12 +382,11 @@ __global__ void __launch_bounds__(256) k64_strided(uint64_t* data, Pass64 g, typ
     W rF[8], rI[8];
     load_roots<F>(rF, rI, fc);
     const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (tid >= g.n_threads) return;
-    const uint64_t c = tid % g.inner;
-    const uint64_t rest = tid / g.inner;
-    const uint64_t jq = rest % g.cq, blk = rest / g.cq;
-    uint64_t* base = data + ((blk * g.cq * R + jq) * g.inner + c);
-    const uint64_t step = g.cq * g.inner;
+    if (tid >= g.n_blocks * g.columns) return;
+    const uint64_t col = tid % g.columns, blk = tid / g.columns;
+    const uint64_t jq = pass_jq(g, col);
+    uint64_t* base = data + (blk * g.block_stride + col);
+    const uint64_t step = g.step;
     V x[16];
 #pragma unroll
     for (int r = 0; r < R; ++r) x[r] = f.from_mem(base[(uint64_t)r * step]);
