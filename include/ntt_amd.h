@@ -130,13 +130,28 @@ uint32_t ntt_crt_prime(int prime_index);
  * ntt64_twiddle_device: data[r][c] *= w^(+-k(r) * (col0+c)), w of order 2^log_root, for a rows x cols
  *   tile whose first row/column are row0/col0 of the four-step matrix; k(r) = row0+r, bit-reversed
  *   over row_bits bits when rows_bitrev != 0 (the order a forward row-axis transform leaves).
- * ntt64_pointwise_device: a[i] = a[i]*b[i]*2^-64 mod p (the factor is undone by ntt64_finalize_device).
+ * ntt64_fourstep_rows_device: the row-axis half of a four-step transform of length 2^log_total on a column slab
+ *   [2^log_rows][cols_local] holding columns col0 .. col0+cols_local-1 of the 2^log_rows x 2^(log_total-log_rows) matrix
+ *   (element i = j + C*r at row r, column j): the first log_rows levels of the long transform, i.e. the transforms
+ *   along the rows axis AND the twiddles w^(j*k) that join the two axes, in the same passes over memory.  Inverse: the
+ *   mirror (twiddles first).  cols_local must be a power of two.  This plus one all-to-all plus
+ * ntt64_fourstep_cols_device is the whole transform: it runs the remaining log_cols levels on the layout the
+ *   all-to-all of column slabs leaves, without re-tiling: 2^log_parts parts (one per sending rank, at most 16),
+ *   part_stride words apart, each holding `rows` rows of 2^(log_cols-log_parts) consecutive columns.  `rows` may be a
+ *   sub-range of a part (pass d_rows + first_row * 2^(log_cols-log_parts)), so that arriving chunks can be transformed
+ *   while later ones are still in flight.
+ * ntt64_pointwise_device: a[i] = a[i]*b[i]*c mod p, c a constant of the arithmetic in use for p (2^-64 in Montgomery
+ *   integers, 1 in double precision) that ntt64_finalize_device undoes.
  * ntt64_load_device: dst[row][i] = i < n ? src[row*src_stride + i] mod p : 0, i < len (may be in place).
  * ntt64_finalize_device: out[row*out_stride + i] = data[row*len + i] * 2^-log_total * 2^64 mod p, canonical.
  * ntt64_poly_multiply_device: the whole product on one GPU: d_out[0..2n-2] = a*b mod p.  Same results
  *   as the CRT route of ntt_poly_multiply_batched_device_u64 wherever both apply. */
 int ntt64_transform_device(uint64_t *d_data, uint64_t p, int log_root, int log_len, size_t inner, size_t outer,
                            int inverse, void *stream);
+int ntt64_fourstep_rows_device(uint64_t *d_slab, uint64_t p, int log_total, int log_rows, size_t cols_local, uint64_t col0,
+                               int inverse, void *stream);
+int ntt64_fourstep_cols_device(uint64_t *d_rows, uint64_t p, int log_total, int log_cols, int log_parts, size_t part_stride,
+                               size_t rows, int inverse, void *stream);
 int ntt64_twiddle_device(uint64_t *d_data, uint64_t p, int log_root, size_t rows, size_t cols, uint64_t row0,
                          uint64_t col0, int row_bits, int rows_bitrev, int inverse, void *stream);
 int ntt64_pointwise_device(uint64_t *d_a, const uint64_t *d_b, size_t count, uint64_t p, int log_root, void *stream);

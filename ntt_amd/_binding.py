@@ -25,7 +25,7 @@ EXPORTS = [
     "ntt_workspace_bytes", "ntt_poly_multiply_batched_device", "ntt_poly_multiply_batched_device_u64",
     "ntt_poly_multiply_batched_device_noalloc",
     "ntt_crt_merge_device", "ntt_crt_residue_product_device", "ntt_crt_prime", "ntt_describe_plan",
-    "ntt64_transform_device", "ntt64_twiddle_device", "ntt64_pointwise_device", "ntt64_load_device",
+    "ntt64_transform_device", "ntt64_fourstep_rows_device", "ntt64_fourstep_cols_device", "ntt64_twiddle_device", "ntt64_pointwise_device", "ntt64_load_device",
     "ntt64_finalize_device", "ntt64_workspace_bytes", "ntt64_poly_multiply_device",
     "ntt_transform_u64", "ntt_transform_device_u64",
     "ntt_io_read_header", "ntt_io_read_in", "ntt_io_check_out", "ntt_io_read_out", "ntt_io_write_out",
@@ -78,6 +78,8 @@ class NttLibrary:
         L.ntt_describe_plan.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t]; L.ntt_describe_plan.restype = ctypes.c_int
         vp, u64, sz, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int
         L.ntt64_transform_device.argtypes = [vp, u64, ci, ci, sz, sz, ci, vp]; L.ntt64_transform_device.restype = ci
+        L.ntt64_fourstep_rows_device.argtypes = [vp, u64, ci, ci, sz, u64, ci, vp]; L.ntt64_fourstep_rows_device.restype = ci
+        L.ntt64_fourstep_cols_device.argtypes = [vp, u64, ci, ci, ci, sz, sz, ci, vp]; L.ntt64_fourstep_cols_device.restype = ci
         L.ntt64_twiddle_device.argtypes = [vp, u64, ci, sz, sz, u64, u64, ci, ci, ci, vp]; L.ntt64_twiddle_device.restype = ci
         L.ntt64_pointwise_device.argtypes = [vp, vp, sz, u64, ci, vp]; L.ntt64_pointwise_device.restype = ci
         L.ntt64_load_device.argtypes = [vp, sz, sz, vp, sz, sz, u64, ci, vp]; L.ntt64_load_device.restype = ci

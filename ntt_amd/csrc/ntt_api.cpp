@@ -1573,6 +1573,38 @@ int ntt64_transform_device(uint64_t* d_data, uint64_t p, int log_root, int log_l
     return transform64(*pl, d_data, log_len, inner, outer, inverse != 0, (hipStream_t)stream);
 }
 
+int ntt64_fourstep_rows_device(uint64_t* d_slab, uint64_t p, int log_total, int log_rows, size_t cols_local, uint64_t col0,
+                               int inverse, void* stream) {
+    if (!d_slab) return fail(NTT_ERR_ARG, "null pointer");
+    if (log_rows < 0 || log_rows > log_total || cols_local == 0 || !is_pow2(cols_local)) return fail(NTT_ERR_ARG, "slab shape: 0 <= log_rows <= log_total, cols_local a power of two");
+    const int log_cols = log_total - log_rows;
+    if (col0 + cols_local > ((uint64_t)1 << log_cols)) return fail(NTT_ERR_ARG, "slab columns exceed the matrix");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    Plan64* pl = nullptr;
+    if ((rc = get_plan64(dev, p, log_total, &pl)) != NTT_OK) return rc;
+    Axis64 ax;
+    ax.log_len = log_rows; ax.inner = cols_local; ax.outer = 1; ax.col_bits = log_cols; ax.col0 = col0;
+    if (log_cols == 0) { ax.col_bits = 0; ax.col0 = 0; }   // a matrix of one column is a plain transform
+    return transform64_axis(*pl, d_slab, ax, inverse != 0, (hipStream_t)stream);
+}
+
+int ntt64_fourstep_cols_device(uint64_t* d_rows, uint64_t p, int log_total, int log_cols, int log_parts, size_t part_stride,
+                               size_t rows, int inverse, void* stream) {
+    if (!d_rows) return fail(NTT_ERR_ARG, "null pointer");
+    if (log_cols < 0 || log_cols > log_total || log_parts < 0 || log_parts > log_cols) return fail(NTT_ERR_ARG, "bad shape");
+    if (log_parts > 0 && part_stride < (rows << (log_cols - log_parts))) return fail(NTT_ERR_ARG, "part stride smaller than a part");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    Plan64* pl = nullptr;
+    if ((rc = get_plan64(dev, p, log_total, &pl)) != NTT_OK) return rc;
+    return transform64_split(*pl, d_rows, log_cols, log_parts, (uint64_t)part_stride, (uint64_t)rows, inverse != 0, (hipStream_t)stream);
+}
+
 int ntt64_twiddle_device(uint64_t* d_data, uint64_t p, int log_root, size_t rows, size_t cols, uint64_t row0, uint64_t col0,
                          int row_bits, int rows_bitrev, int inverse, void* stream) {
     if (!d_data) return fail(NTT_ERR_ARG, "null pointer");

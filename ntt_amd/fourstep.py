@@ -1,18 +1,22 @@
 """One very long polynomial product by a four-step transform, on one GPU or sharded over ranks.
 
 The length-L transform (L = 2^l >= 2n-1) is viewed as an R x C matrix, element i = j + C*r:
-  1. every rank holds a slab of columns [R][C/G] and transforms it along the row axis (length R),
-  2. multiplies by the twiddles w_L^(j*k1),
-  3. one all-to-all turns column slabs into row slabs [R/G][C],
-  4. each row is transformed along the column axis (length C).
-The spectra of both operands end up in the same (scrambled) order, the pointwise product is
-local, and the inverse runs the mirror sequence: three all-to-alls per product in total.
-This replaces the reference's distributed transform, which keeps the whole array on every rank
-and all-reduces it after every butterfly stage (main_mpi_t.cc:164-222).
+  1. every rank holds a slab of columns [R][C/G] and runs the first log2 R levels of the long transform on it
+     (`ntt64_fourstep_rows_device`: the transforms along the rows axis together with the twiddles w_L^(j*k1)
+     that join the two axes, in the same passes over memory);
+  2. ONE all-to-all turns column slabs into row slabs.  The send side needs no packing (rows g*R/G.. of the slab
+     are the chunk for rank g) and the receive side no re-tiling: the remaining levels run directly on the
+     [G][R/G][C/G] layout the exchange leaves (`ntt64_fourstep_cols_device`);
+  3. the exchange is issued in `chunks` pieces of rows, so that the column-axis transforms of a piece run while
+     the later pieces are still on the links.
+The spectra of both operands end up in the same (scrambled) order, the pointwise product is local, and the
+inverse runs the mirror sequence: three all-to-alls per product in total, each moving (G-1)/G of the rank's
+slab.  Everything is ordered on the device stream; the host never waits between the steps.
+This replaces the reference's distributed transform, which keeps the whole array on every rank and all-reduces
+it after every butterfly stage (main_mpi_t.cc:164-222).
 
-All arithmetic is done by the library's 64-bit-field kernels through its C ABI; torch is used
-for device memory, the local re-tiling around the all-to-all and the collective itself
-(RCCL on GPUs, gloo on CPU in the tests)."""
+All arithmetic is done by the library's 64-bit-field kernels through its C ABI; torch provides device memory
+and the collective (RCCL on GPUs, gloo on CPU in the tests)."""
 import numpy as np
 
 
@@ -35,14 +39,20 @@ def plan_shape(n, world):
 class FourStep:
     """Four-step product context of one rank.  lib: NttLibrary; dist: torch.distributed or None."""
 
-    def __init__(self, lib, p, n, device, dist=None):
+    def __init__(self, lib, p, n, device, dist=None, chunks=4):
         import torch
         self.torch, self.lib, self.p, self.n, self.device, self.dist = torch, lib, int(p), int(n), device, dist
         self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        if self.world > 16:
+            raise ValueError("the split layout of the column pass supports at most 16 ranks")
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.log_total, self.log_rows, self.log_cols = plan_shape(n, self.world)
         self.R, self.C = 1 << self.log_rows, 1 << self.log_cols
         self.Cl, self.Rl = self.C // self.world, self.R // self.world
+        self.log_parts = _log2(self.world)
+        self.chunks = max(1, min(int(chunks), self.Rl)) if self.world > 1 else 1
+        while self.Rl % self.chunks:
+            self.chunks -= 1
         self.stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else None
 
     # -- data placement ---------------------------------------------------------------
@@ -55,53 +65,66 @@ class FourStep:
         slab = v.reshape(self.R, self.C)[:, self.rank * self.Cl:(self.rank + 1) * self.Cl]
         return t.from_numpy(np.ascontiguousarray(slab).view(np.int64)).to(self.device)
 
-    def _sync(self):
-        if self.device.type == "cuda":
-            self.torch.cuda.synchronize(self.device)
+    def _exchange(self, send, recv, rows):
+        """All-to-all of rows [rows[0], rows[1]) of every rank's chunk: send / recv are [G][Rl][Cl] arrays, chunk g of
+        `send` goes to rank g and chunk g of `recv` comes from it.  Written as one batch of point-to-point transfers
+        (what an all-to-all is on RCCL: a group of sends and receives over all xGMI links at once), so that the pieces
+        need no packing and the same code runs on gloo.  Returns the pending transfers."""
+        lo, hi = rows
+        recv[self.rank, lo:hi].copy_(send[self.rank, lo:hi])
+        ops = []
+        for g in range(self.world):
+            if g != self.rank:
+                ops.append(self.dist.P2POp(self.dist.irecv, recv[g, lo:hi], g))
+                ops.append(self.dist.P2POp(self.dist.isend, send[g, lo:hi], g))
+        return self.dist.batch_isend_irecv(ops) if ops else []
 
-    def _columns_to_rows(self, x):
-        """[R][Cl] column slab -> [Rl][C] row slab (all-to-all + local re-tiling)."""
-        t = self.torch
-        if self.world == 1:
-            return x
-        send = x.contiguous()                       # rows g*Rl..(g+1)*Rl-1 are the chunk for rank g
-        recv = t.empty_like(send)
-        self._sync()
-        self.dist.all_to_all_single(recv, send)
-        # recv[g''] = [Rl][Cl] tile holding columns of rank g'' -> interleave into [Rl][G*Cl]
-        return recv.view(self.world, self.Rl, self.Cl).permute(1, 0, 2).contiguous().view(self.Rl, self.C)
-
-    def _rows_to_columns(self, z):
-        t = self.torch
-        if self.world == 1:
-            return z
-        send = z.view(self.Rl, self.world, self.Cl).permute(1, 0, 2).contiguous()
-        recv = t.empty_like(send)
-        self._sync()
-        self.dist.all_to_all_single(recv, send)
-        return recv.view(self.R, self.Cl)
+    def _row_pieces(self):
+        per = self.Rl // self.chunks
+        return [(k * per, (k + 1) * per) for k in range(self.chunks)]
 
     # -- transforms ---------------------------------------------------------------------
     def forward(self, slab):
-        """Column slab (values any 64-bit) -> row slab of the spectrum, scrambled order."""
-        L, lib, p, lr = self.lib.lib, self.lib, self.p, self.log_total
+        """Column slab [R][Cl] (any 64-bit values) -> spectrum in the received layout [G][Rl][Cl], scrambled order."""
+        L, lib, p, lt = self.lib.lib, self.lib, self.p, self.log_total
         x = slab
-        lib.check(L.ntt64_load_device(x.data_ptr(), 0, x.numel(), x.data_ptr(), x.numel(), 1, p, lr, self.stream))
-        lib.check(L.ntt64_transform_device(x.data_ptr(), p, lr, self.log_rows, self.Cl, 1, 0, self.stream))
-        lib.check(L.ntt64_twiddle_device(x.data_ptr(), p, lr, self.R, self.Cl, 0, self.rank * self.Cl, self.log_rows, 1, 0, self.stream))
-        z = self._columns_to_rows(x)
-        lib.check(L.ntt64_transform_device(z.data_ptr(), p, lr, self.log_cols, 1, self.Rl, 0, self.stream))
-        return z
+        lib.check(L.ntt64_load_device(x.data_ptr(), 0, x.numel(), x.data_ptr(), x.numel(), 1, p, lt, self.stream))
+        lib.check(L.ntt64_fourstep_rows_device(x.data_ptr(), p, lt, self.log_rows, self.Cl, self.rank * self.Cl, 0, self.stream))
+        if self.world == 1:
+            lib.check(L.ntt64_fourstep_cols_device(x.data_ptr(), p, lt, self.log_cols, 0, 0, self.R, 0, self.stream))
+            return x
+        send = x.view(self.world, self.Rl, self.Cl)
+        recv = self.torch.empty_like(send)
+        pieces = self._row_pieces()
+        works = [self._exchange(send, recv, rows) for rows in pieces]          # all issued behind the row pass
+        for pending, (lo, hi) in zip(works, pieces):
+            for w in pending:
+                w.wait()                                                        # orders the stream, not the host, on GPUs
+            lib.check(L.ntt64_fourstep_cols_device(recv.data_ptr() + 8 * lo * self.Cl, p, lt, self.log_cols, self.log_parts,
+                                                   self.Rl * self.Cl, hi - lo, 0, self.stream))
+        return recv
 
     def inverse(self, z):
-        """Row slab of a spectrum -> column slab of canonical coefficients [R][Cl] (c[j + C*r])."""
-        L, lib, p, lr = self.lib.lib, self.lib, self.p, self.log_total
-        lib.check(L.ntt64_transform_device(z.data_ptr(), p, lr, self.log_cols, 1, self.Rl, 1, self.stream))
-        x = self._rows_to_columns(z)
-        lib.check(L.ntt64_twiddle_device(x.data_ptr(), p, lr, self.R, self.Cl, 0, self.rank * self.Cl, self.log_rows, 1, 1, self.stream))
-        lib.check(L.ntt64_transform_device(x.data_ptr(), p, lr, self.log_rows, self.Cl, 1, 1, self.stream))
+        """Spectrum in the received layout -> column slab of canonical coefficients [R][Cl] (c[j + C*r])."""
+        L, lib, p, lt = self.lib.lib, self.lib, self.p, self.log_total
+        if self.world == 1:
+            lib.check(L.ntt64_fourstep_cols_device(z.data_ptr(), p, lt, self.log_cols, 0, 0, self.R, 1, self.stream))
+            x = z.view(self.R, self.Cl)
+        else:
+            z = z.view(self.world, self.Rl, self.Cl)
+            back = self.torch.empty_like(z)
+            works = []
+            for lo, hi in self._row_pieces():
+                lib.check(L.ntt64_fourstep_cols_device(z.data_ptr() + 8 * lo * self.Cl, p, lt, self.log_cols, self.log_parts,
+                                                       self.Rl * self.Cl, hi - lo, 1, self.stream))
+                works.append(self._exchange(z, back, (lo, hi)))                # travels while the next piece is transformed
+            for pending in works:
+                for w in pending:
+                    w.wait()
+            x = back.view(self.R, self.Cl)
+        lib.check(L.ntt64_fourstep_rows_device(x.data_ptr(), p, lt, self.log_rows, self.Cl, self.rank * self.Cl, 1, self.stream))
         out = self.torch.empty_like(x)
-        lib.check(L.ntt64_finalize_device(x.data_ptr(), x.numel(), out.data_ptr(), 0, x.numel(), 1, p, lr, self.log_total, self.stream))
+        lib.check(L.ntt64_finalize_device(x.data_ptr(), x.numel(), out.data_ptr(), 0, x.numel(), 1, p, lt, self.log_total, self.stream))
         return out
 
     def multiply_slabs(self, a_slab, b_slab):
@@ -111,21 +134,28 @@ class FourStep:
         self.lib.check(self.lib.lib.ntt64_pointwise_device(za.data_ptr(), zb.data_ptr(), za.numel(), self.p, self.log_total, self.stream))
         return self.inverse(za)
 
-    def gather(self, slab):
-        """All ranks' column slabs -> the full product (numpy uint64, 2n-1 values) on every rank."""
+    def gather(self, slab, all_ranks=False):
+        """The ranks' column slabs -> the full product (numpy uint64, 2n-1 values) on rank 0 (None elsewhere), or on every
+        rank with all_ranks=True.  A product this long normally stays sharded; this is for checking."""
         t = self.torch
-        self._sync()
+        slab = slab.contiguous()
         if self.world > 1:
-            parts = [t.empty_like(slab) for _ in range(self.world)]
-            self.dist.all_gather(parts, slab.contiguous())
+            if all_ranks:
+                parts = [t.empty_like(slab) for _ in range(self.world)]
+                self.dist.all_gather(parts, slab)
+            else:
+                parts = [t.empty_like(slab) for _ in range(self.world)] if self.rank == 0 else None
+                self.dist.gather(slab, parts, dst=0)
+                if self.rank != 0:
+                    return None
             full = t.cat(parts, dim=1)
         else:
             full = slab
         return full.cpu().numpy().view(np.uint64).reshape(-1)[: 2 * self.n - 1].copy()
 
 
-def poly_multiply_fourstep(lib, a, b, p, device, dist=None):
-    """Full product of two numpy uint64 coefficient vectors (identical on every rank)."""
-    fs = FourStep(lib, p, len(a), device, dist)
+def poly_multiply_fourstep(lib, a, b, p, device, dist=None, chunks=4):
+    """Full product of two numpy uint64 coefficient vectors (identical on every rank), returned on every rank."""
+    fs = FourStep(lib, p, len(a), device, dist, chunks)
     c = fs.multiply_slabs(fs.column_slab(np.asarray(a, dtype=np.uint64)), fs.column_slab(np.asarray(b, dtype=np.uint64)))
-    return fs.gather(c)
+    return fs.gather(c, all_ranks=True)

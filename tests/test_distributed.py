@@ -78,11 +78,18 @@ flag = torch.tensor([1 if ok3 else 0]); dist.all_reduce(flag, op=dist.ReduceOp.M
 #    all-to-all between the two transform axes (3 per product)
 from ntt_amd.fourstep import poly_multiply_fourstep
 ok4 = True
-for n4 in (4096, 1000, 16384):
+for n4 in (4096, 1000, 16384, 70000):
     A4 = rng.integers(0, P, n4, dtype=np.uint64); B4 = rng.integers(0, P, n4, dtype=np.uint64)
     got = poly_multiply_fourstep(lib, A4, B4, P, torch.device("cpu"), dist)
     want = orc.crt_ntt_multiply(A4, B4, P) if n4 & (n4 - 1) == 0 else orc.schoolbook_u64(A4, B4, P)
     ok4 = ok4 and np.array_equal(got, want)
+# rank 0 only: the product gathered to one rank, the usual way to look at a sharded result
+from ntt_amd.fourstep import FourStep
+fs = FourStep(lib, P, 5000, torch.device("cpu"), dist, chunks=2)
+A6 = rng.integers(0, P, 5000, dtype=np.uint64); B6 = rng.integers(0, P, 5000, dtype=np.uint64)
+got6 = fs.gather(fs.multiply_slabs(fs.column_slab(A6), fs.column_slab(B6)))
+ok4 = ok4 and (np.array_equal(got6, orc.schoolbook_u64(A6, B6, P)) if rank == 0 else got6 is None)
+flag = torch.tensor([1 if ok4 else 0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN); ok4 = bool(flag.item())   # every rank's verdict
 slow = max_over_ranks(float(rank + 1), dist)
 if rank == 0:
     print(json.dumps({"batched": bool(ok1), "crt": bool(ok2), "crt_packaged": bool(ok3), "fourstep": bool(ok4), "max": slow, "world": world}))
