@@ -40,6 +40,11 @@ namespace {
 
 thread_local std::string g_err;
 
+// Every entry point of the C ABI takes this lock: the library's state (device table, plan caches, workspaces) is shared,
+// so concurrent callers are serialised rather than left to race.  Recursive, because entry points call one another.
+std::recursive_mutex g_api_mutex;
+#define NTT_API_LOCK std::lock_guard<std::recursive_mutex> api_lock_(g_api_mutex)
+
 int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
@@ -999,7 +1004,28 @@ thread_local bool t_inline_copies = false;
 
 class CopyPool {
   public:
-    static CopyPool& get() { static CopyPool* p = new CopyPool(); return *p; }  // never destroyed: workers may outlive main
+    // Created on first use, stopped and joined by ntt_shutdown() (and created again by the next call that needs it).  A
+    // process that exits without ntt_shutdown() leaves the workers blocked on their condition variable: the instance
+    // is deliberately never destroyed by a static destructor.
+    static CopyPool& get() {
+        std::lock_guard<std::mutex> lk(instance_mutex());
+        if (!instance()) instance() = new CopyPool();
+        return *instance();
+    }
+    static void shutdown() {
+        std::lock_guard<std::mutex> lk(instance_mutex());
+        CopyPool* p = instance();
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk2(p->m_);
+            p->stop_ = true;
+            ++p->generation_;
+        }
+        p->cv_work_.notify_all();
+        for (auto& t : p->workers_) t.join();
+        delete p;
+        instance() = nullptr;
+    }
     void copy(void* dst, const void* src, size_t bytes, size_t piece = (size_t)1 << 20) {
         int parts = (int)((bytes + piece - 1) / piece);
         if (parts > (int)workers_.size() + 1) parts = (int)workers_.size() + 1;
@@ -1035,8 +1061,9 @@ class CopyPool {
         const char* forced = getenv("NTT_COPY_WORKERS");   // test hook: exact number of helper threads (0..15)
         if (forced && forced[0] >= '0' && forced[0] <= '9') n = atoi(forced) > 15 ? 15 : atoi(forced);
         for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
-        for (auto& t : workers_) t.detach();
     }
+    static CopyPool*& instance() { static CopyPool* p = nullptr; return p; }
+    static std::mutex& instance_mutex() { static std::mutex m; return m; }
     void run(int parts, const std::function<void(int)>& fn) {
         {
             std::lock_guard<std::mutex> lk(m_);
@@ -1069,6 +1096,7 @@ class CopyPool {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_work_.wait(lk, [&] { return generation_ != seen; });
                 seen = generation_;
+                if (stop_) return;
             }
             work();
         }
@@ -1079,6 +1107,7 @@ class CopyPool {
     const std::function<void(int)>* fn_ = nullptr;
     int parts_ = 0, next_ = 0, remaining_ = 0;
     uint64_t generation_ = 0;
+    bool stop_ = false;
 };
 
 size_t stage_limit_bytes() {  // NTT_STAGE_LIMIT_MB: test hook, lets small calls exercise the chunked path
@@ -1344,9 +1373,11 @@ void die(const char* fn) {
 
 extern "C" {
 
-int ntt_init(int n_gpus) { return do_init(n_gpus); }
+int ntt_init(int n_gpus) {
+    NTT_API_LOCK; return do_init(n_gpus); }
 
 void ntt_shutdown(void) {
+    NTT_API_LOCK;
     for (auto& kvd : g_devs) {
         Device* dev = kvd.second.get();
         hipError_t e = hipSetDevice(dev->id);
@@ -1367,18 +1398,22 @@ void ntt_shutdown(void) {
     }
     g_devs.clear();
     g_inited = false;
+    CopyPool::shutdown();
     g_prof.clear(); g_prof_used = 0; g_prof_on = false;
     for (hipEvent_t ev : g_prof_pool) { hipError_t e = hipEventDestroy(ev); (void)e; }
     g_prof_pool.clear();
 }
 
-int ntt_device_count(void) { return g_inited ? g_visible : 0; }
+int ntt_device_count(void) {
+    NTT_API_LOCK; return g_inited ? g_visible : 0; }
 
 const char* ntt_last_error(void) { return g_err.c_str(); }
 
-uint32_t ntt_crt_prime(int i) { return (i >= 0 && i < 4) ? kCrtPrimes[i] : 0; }
+uint32_t ntt_crt_prime(int i) {
+    NTT_API_LOCK; return (i >= 0 && i < 4) ? kCrtPrimes[i] : 0; }
 
 size_t ntt_workspace_bytes(int n, uint64_t p, size_t batch) {
+    NTT_API_LOCK;
     if (n < 1) return 0;
     int logL = ceil_log2(2 * (uint64_t)n - 1);
     if (logL < 1) logL = 1;
@@ -1394,6 +1429,7 @@ size_t ntt_workspace_bytes(int n, uint64_t p, size_t batch) {
 int ntt_poly_multiply_batched_device(const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_ab, int n, uint32_t p, size_t batch,
                                      size_t a_stride, size_t b_stride, size_t ab_stride, void* workspace,
                                      size_t workspace_bytes, void* stream) {
+    NTT_API_LOCK;
     int rc = check_args(d_a, d_b, d_ab, n, batch);
     if (rc != NTT_OK) return rc;
     if (a_stride < (size_t)n || b_stride < (size_t)n || ab_stride < (size_t)(2 * n - 1)) return fail(NTT_ERR_ARG, "row stride too small");
@@ -1414,6 +1450,7 @@ int ntt_poly_multiply_batched_device(const uint32_t* d_a, const uint32_t* d_b, u
 // is a lookup only (no plan is built, no stream or buffer created), and the intermediates go to the static scratch.
 int ntt_poly_multiply_batched_device_noalloc(const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_ab, int n, uint32_t p,
                                              size_t batch, size_t a_stride, size_t b_stride, size_t ab_stride, void* stream) {
+    NTT_API_LOCK;
     int rc = check_args(d_a, d_b, d_ab, n, batch);
     if (rc != NTT_OK) return rc;
     if (a_stride < (size_t)n || b_stride < (size_t)n || ab_stride < (size_t)(2 * n - 1)) return fail(NTT_ERR_ARG, "row stride too small");
@@ -1445,6 +1482,7 @@ int ntt_poly_multiply_batched_device_noalloc(const uint32_t* d_a, const uint32_t
 int ntt_poly_multiply_batched_device_u64(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_ab, int n, uint64_t p,
                                          size_t batch, size_t a_stride, size_t b_stride, size_t ab_stride, void* workspace,
                                          size_t workspace_bytes, void* stream) {
+    NTT_API_LOCK;
     int rc = check_args(d_a, d_b, d_ab, n, batch);
     if (rc != NTT_OK) return rc;
     if (a_stride < (size_t)n || b_stride < (size_t)n || ab_stride < (size_t)(2 * n - 1)) return fail(NTT_ERR_ARG, "row stride too small");
@@ -1472,6 +1510,7 @@ int ntt_poly_multiply_batched_device_u64(const uint64_t* d_a, const uint64_t* d_
 }
 
 int ntt_crt_merge_device(const uint32_t* d_res, size_t res_stride, uint64_t* d_out, size_t count, uint64_t p, void* stream) {
+    NTT_API_LOCK;
     if (!d_res || !d_out) return fail(NTT_ERR_ARG, "null pointer");
     int rc = do_init(0);
     if (rc != NTT_OK) return rc;
@@ -1487,6 +1526,7 @@ int ntt_crt_merge_device(const uint32_t* d_res, size_t res_stride, uint64_t* d_o
 int ntt_crt_residue_product_device(const uint64_t* d_a, const uint64_t* d_b, uint32_t* d_res, int n, int prime_index,
                                    size_t batch, size_t a_stride, size_t b_stride, size_t res_stride, void* workspace,
                                    size_t workspace_bytes, void* stream) {
+    NTT_API_LOCK;
     int rc = check_args(d_a, d_b, d_res, n, batch);
     if (rc != NTT_OK) return rc;
     if (prime_index < 0 || prime_index > 3) return fail(NTT_ERR_ARG, "prime_index must be 0..3");
@@ -1500,6 +1540,7 @@ int ntt_crt_residue_product_device(const uint64_t* d_a, const uint64_t* d_b, uin
 }
 
 int ntt_poly_multiply_batched(const uint32_t* a, const uint32_t* b, uint32_t* ab, int n, uint32_t p, size_t batch, int n_gpus) {
+    NTT_API_LOCK;
     int rc = check_args(a, b, ab, n, batch);
     if (rc != NTT_OK) return rc;
     if (!direct_path_ok(p, transform_log2(n))) {
@@ -1516,6 +1557,7 @@ int ntt_poly_multiply_batched(const uint32_t* a, const uint32_t* b, uint32_t* ab
 }
 
 int ntt_poly_multiply_batched_u64(const uint64_t* a, const uint64_t* b, uint64_t* ab, int n, uint64_t p, size_t batch, int n_gpus) {
+    NTT_API_LOCK;
     int rc = check_args(a, b, ab, n, batch);
     if (rc != NTT_OK) return rc;
     std::string why;
@@ -1534,10 +1576,12 @@ int ntt_poly_multiply_batched_u64(const uint64_t* a, const uint64_t* b, uint64_t
 }
 
 int ntt_poly_multiply_u64(const uint64_t* a, const uint64_t* b, uint64_t* ab, int n, uint64_t p) {
+    NTT_API_LOCK;
     return ntt_poly_multiply_batched_u64(a, b, ab, n, p, 1, 1);
 }
 
 int ntt_poly_multiply_i32(const int* a, const int* b, int* ab, int n, int p) {
+    NTT_API_LOCK;
     if (p < 2) return fail(NTT_ERR_ARG, "modulus must be positive");
     int rc = check_args(a, b, ab, n, 1);
     if (rc != NTT_OK) return rc;
@@ -1553,16 +1597,19 @@ int ntt_poly_multiply_i32(const int* a, const int* b, int* ab, int n, int p) {
 }
 
 void poly_multiply(const int* a, const int* b, int* ab, int n, int p) {
+    NTT_API_LOCK;
     if (ntt_poly_multiply_i32(a, b, ab, n, p) != NTT_OK) die("poly_multiply");
 }
 
 void poly_multiply_u64(const uint64_t* a, const uint64_t* b, uint64_t* ab, int n, uint64_t p) {
+    NTT_API_LOCK;
     if (ntt_poly_multiply_u64(a, b, ab, n, p) != NTT_OK) die("poly_multiply_u64");
 }
 
 // ---- 64-bit field entry points -------------------------------------------------------------
 int ntt64_transform_device(uint64_t* d_data, uint64_t p, int log_root, int log_len, size_t inner, size_t outer, int inverse,
                            void* stream) {
+    NTT_API_LOCK;
     if (!d_data) return fail(NTT_ERR_ARG, "null pointer");
     int rc = do_init(0);
     if (rc != NTT_OK) return rc;
@@ -1575,6 +1622,7 @@ int ntt64_transform_device(uint64_t* d_data, uint64_t p, int log_root, int log_l
 
 int ntt64_fourstep_rows_device(uint64_t* d_slab, uint64_t p, int log_total, int log_rows, size_t cols_local, uint64_t col0,
                                int inverse, void* stream) {
+    NTT_API_LOCK;
     if (!d_slab) return fail(NTT_ERR_ARG, "null pointer");
     if (log_rows < 0 || log_rows > log_total || cols_local == 0 || !is_pow2(cols_local)) return fail(NTT_ERR_ARG, "slab shape: 0 <= log_rows <= log_total, cols_local a power of two");
     const int log_cols = log_total - log_rows;
@@ -1593,6 +1641,7 @@ int ntt64_fourstep_rows_device(uint64_t* d_slab, uint64_t p, int log_total, int 
 
 int ntt64_fourstep_cols_device(uint64_t* d_rows, uint64_t p, int log_total, int log_cols, int log_parts, size_t part_stride,
                                size_t rows, int inverse, void* stream) {
+    NTT_API_LOCK;
     if (!d_rows) return fail(NTT_ERR_ARG, "null pointer");
     if (log_cols < 0 || log_cols > log_total || log_parts < 0 || log_parts > log_cols) return fail(NTT_ERR_ARG, "bad shape");
     if (log_parts > 0 && part_stride < (rows << (log_cols - log_parts))) return fail(NTT_ERR_ARG, "part stride smaller than a part");
@@ -1607,6 +1656,7 @@ int ntt64_fourstep_cols_device(uint64_t* d_rows, uint64_t p, int log_total, int 
 
 int ntt64_twiddle_device(uint64_t* d_data, uint64_t p, int log_root, size_t rows, size_t cols, uint64_t row0, uint64_t col0,
                          int row_bits, int rows_bitrev, int inverse, void* stream) {
+    NTT_API_LOCK;
     if (!d_data) return fail(NTT_ERR_ARG, "null pointer");
     int rc = do_init(0);
     if (rc != NTT_OK) return rc;
@@ -1621,6 +1671,7 @@ int ntt64_twiddle_device(uint64_t* d_data, uint64_t p, int log_root, size_t rows
 }
 
 int ntt64_pointwise_device(uint64_t* d_a, const uint64_t* d_b, size_t count, uint64_t p, int log_root, void* stream) {
+    NTT_API_LOCK;
     if (!d_a || !d_b) return fail(NTT_ERR_ARG, "null pointer");
     int rc = do_init(0);
     if (rc != NTT_OK) return rc;
@@ -1636,6 +1687,7 @@ int ntt64_pointwise_device(uint64_t* d_a, const uint64_t* d_b, size_t count, uin
 
 int ntt64_load_device(const uint64_t* d_src, size_t src_stride, size_t n, uint64_t* d_dst, size_t len, size_t rows, uint64_t p,
                       int log_root, void* stream) {
+    NTT_API_LOCK;
     if (!d_src || !d_dst) return fail(NTT_ERR_ARG, "null pointer");
     int rc = do_init(0);
     if (rc != NTT_OK) return rc;
@@ -1651,6 +1703,7 @@ int ntt64_load_device(const uint64_t* d_src, size_t src_stride, size_t n, uint64
 
 int ntt64_finalize_device(const uint64_t* d_data, size_t len, uint64_t* d_out, size_t out_stride, size_t n_out, size_t rows,
                           uint64_t p, int log_root, int log_total, void* stream) {
+    NTT_API_LOCK;
     if (!d_data || !d_out) return fail(NTT_ERR_ARG, "null pointer");
     int rc = do_init(0);
     if (rc != NTT_OK) return rc;
@@ -1668,6 +1721,7 @@ int ntt64_finalize_device(const uint64_t* d_data, size_t len, uint64_t* d_out, s
 }
 
 size_t ntt64_workspace_bytes(size_t n) {
+    NTT_API_LOCK;
     if (n < 1) return 0;
     const int logL = ceil_log2(2 * (uint64_t)n - 1) < 1 ? 1 : ceil_log2(2 * (uint64_t)n - 1);
     return 2 * ((size_t)1 << logL) * sizeof(uint64_t);
@@ -1675,6 +1729,7 @@ size_t ntt64_workspace_bytes(size_t n) {
 
 int ntt64_poly_multiply_device(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n, uint64_t p, void* workspace,
                                size_t workspace_bytes, void* stream) {
+    NTT_API_LOCK;
     if (!d_a || !d_b || !d_out) return fail(NTT_ERR_ARG, "null pointer");
     if (n < 1 || n > ((size_t)1 << 34)) return fail(NTT_ERR_ARG, "n out of range");
     int rc = do_init(0);
@@ -1686,6 +1741,7 @@ int ntt64_poly_multiply_device(const uint64_t* d_a, const uint64_t* d_b, uint64_
 
 // ---- stand-alone transforms in natural order (the reference's NTT(), main_naive.cc:96-137) ----
 int ntt_transform_device_u64(uint64_t* d_a, size_t n, size_t batch, int invert, uint64_t p, void* stream) {
+    NTT_API_LOCK;
     if (!d_a) return fail(NTT_ERR_ARG, "null pointer");
     if (n < 1 || (n & (n - 1)) != 0) return fail(NTT_ERR_ARG, "transform length must be a power of two");
     int rc = do_init(0);
@@ -1724,6 +1780,7 @@ int ntt_transform_device_u64(uint64_t* d_a, size_t n, size_t batch, int invert, 
 }
 
 int ntt_transform_u64(uint64_t* a, int n, int invert, uint64_t p) {
+    NTT_API_LOCK;
     if (!a || n < 1) return fail(NTT_ERR_ARG, "bad argument");
     int rc = do_init(0);
     if (rc != NTT_OK) return rc;
@@ -1739,6 +1796,7 @@ int ntt_transform_u64(uint64_t* a, int n, int invert, uint64_t p) {
 }
 
 int ntt_profile_enable(int on) {
+    NTT_API_LOCK;
     g_prof.clear();
     g_prof_used = 0;   // the pool's events are reused by the next session
     g_prof_on = on != 0;
@@ -1746,6 +1804,7 @@ int ntt_profile_enable(int on) {
 }
 
 int ntt_profile_read(char* names, size_t names_len, double* total_ms, int* launches, int max_kernels) {
+    NTT_API_LOCK;
     if (!names || !total_ms || !launches || max_kernels <= 0) return fail(NTT_ERR_ARG, "bad argument");
     std::vector<std::string> labels;
     std::string joined;
@@ -1768,6 +1827,7 @@ int ntt_profile_read(char* names, size_t names_len, double* total_ms, int* launc
 }
 
 int ntt_describe_plan(int n, uint64_t p, char* buf, size_t buf_len) {
+    NTT_API_LOCK;
     if (!buf || buf_len == 0 || n < 1) return fail(NTT_ERR_ARG, "bad argument");
     const int logL = transform_log2(n);
     std::string s, why;
