@@ -302,23 +302,42 @@ __global__ void __launch_bounds__(LOCAL64_T) k64_local(uint64_t* data, const uin
     const int t = threadIdx.x;
     const int ql = ((m - 1) & 3) + 1;
     V v[16];
+    // Full-length chunks (m = 12): the first forward round reads memory in the order its threads need anyway (values
+    // t + 256 k) and the last inverse round writes in it, so the copy through LDS is skipped on that side.
+    const bool direct = m == LOCAL64_LOG;
     for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         uint64_t* base = data + chunk * (uint64_t)LOCAL64_N;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int e = t + LOCAL64_T * i;
+        const uint64_t* base_b = MUL ? other + chunk * (uint64_t)LOCAL64_N : nullptr;
+        auto fetch = [&](int e) -> V {
             V r = f.from_mem(base[e]);
-            if (MUL) r = f.mulpw(r, f.from_mem(other[chunk * (uint64_t)LOCAL64_N + e]));
-            lds[local_slot(e)] = r;
+            if (MUL) r = f.mulpw(r, f.from_mem(base_b[e]));
+            return r;
+        };
+        auto emit = [&](int e, V r) {
+            if (FINAL) {
+                const uint64_t idx = chunk * (uint64_t)LOCAL64_N + e;
+                if (idx < n_out) out[idx] = f.canon(f.twiddled(r, scale));
+            } else {
+                base[e] = f.to_mem(r);
+            }
+        };
+        if (INVERSE || !direct) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const int e = t + LOCAL64_T * i; lds[local_slot(e)] = fetch(e); }
+            __syncthreads();
         }
-        __syncthreads();
         if (!INVERSE) {
             for (int b = m; b > 4; b -= 4) {
                 const int sub = 1 << (b - 4);
                 const int blk = t >> (b - 4), j = t & (sub - 1);
                 const int e0 = (blk << b) + j;
+                if (direct && b == m) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] = lds[local_slot(e0 + k * sub)];
+                    for (int k = 0; k < 16; ++k) v[k] = fetch(e0 + k * sub);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] = lds[local_slot(e0 + k * sub)];
+                }
                 dif_blocks<F, 4>(v, f, rF);
                 const uint64_t* T = rt.f[b] + ((size_t)j << 4);
 #pragma unroll
@@ -332,12 +351,16 @@ __global__ void __launch_bounds__(LOCAL64_T) k64_local(uint64_t* data, const uin
             dif_blocks_rt<F>(ql, v, f, rF);
 #pragma unroll
             for (int i = 0; i < 16; ++i) lds[local_slot((t << 4) + i)] = v[i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const int e = t + LOCAL64_T * i; emit(e, lds[local_slot(e)]); }
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = lds[local_slot((t << 4) + i)];
             dit_blocks_rt<F>(ql, v, f, rI);
 #pragma unroll
             for (int i = 0; i < 16; ++i) lds[local_slot((t << 4) + i)] = v[i];
+            bool stored = false;
             for (int b = ql + 4; b <= m; b += 4) {
                 __syncthreads();
                 const int sub = 1 << (b - 4);
@@ -350,20 +373,19 @@ __global__ void __launch_bounds__(LOCAL64_T) k64_local(uint64_t* data, const uin
                     v[k] = k ? f.twiddled(r, f.tw_from_mem(T[k])) : r;
                 }
                 dit_blocks<F, 4>(v, f, rI);
+                if (direct && b == m) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) lds[local_slot(e0 + k * sub)] = v[k];
+                    for (int k = 0; k < 16; ++k) emit(e0 + k * sub, v[k]);
+                    stored = true;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) lds[local_slot(e0 + k * sub)] = v[k];
+                }
             }
-        }
-        __syncthreads();
+            if (!stored) {
+                __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int e = t + LOCAL64_T * i;
-            const V r = lds[local_slot(e)];
-            if (FINAL) {
-                const uint64_t idx = chunk * (uint64_t)LOCAL64_N + e;
-                if (idx < n_out) out[idx] = f.canon(f.twiddled(r, scale));
-            } else {
-                base[e] = f.to_mem(r);
+                for (int i = 0; i < 16; ++i) { const int e = t + LOCAL64_T * i; emit(e, lds[local_slot(e)]); }
             }
         }
         __syncthreads();   // the next chunk overwrites the LDS
