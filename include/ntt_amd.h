@@ -47,6 +47,20 @@ int ntt_device_count(void);
 /* message for the last non-zero status on this thread ("" if none) */
 const char *ntt_last_error(void);
 
+/* How a modulus above 2^31 is served.  The reference splits every such product over four 32-bit NTT primes and merges
+ * the residues with 128-bit arithmetic (CRT_NTT_multiply_serial, main_naive.cc:178-230).  Its one large modulus,
+ * 1337006139375617 = 19 * 2^46 + 1, is itself NTT-friendly, and for such primes up to 1.5e15 the library has a direct
+ * transform in exact double-precision modular arithmetic that gives the same residues at about half the cost.
+ *   NTT_ROUTE_AUTO       (default) the fastest exact route: the direct 64-bit field where the modulus allows it, the
+ *                        four-prime CRT otherwise
+ *   NTT_ROUTE_REFERENCE  the reference's own choice: the four-prime CRT wherever it applies
+ * ntt_set_route_policy returns the previous policy (-1 for an unknown one); it is process-wide and affects the calls
+ * that choose a route themselves (poly_multiply_u64, the *_u64 batched entry points, ntt_workspace_bytes,
+ * ntt_describe_plan), not the explicit per-route entry points below. */
+#define NTT_ROUTE_AUTO 0
+#define NTT_ROUTE_REFERENCE 1
+int ntt_set_route_policy(int policy);
+
 /* Drop-in for the course skeleton's entry point `void poly_multiply(int *a, int *b, int *ab, int n, int p)`
  * (main.cc:92-98, call site main.cc:1268-1269).  Writes ab[0..2n-2]; like every NTT path of the
  * reference it overwrites rather than accumulates.  Aborts the process with a message on failure,
@@ -70,7 +84,7 @@ int ntt_poly_multiply_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, in
 int ntt_poly_multiply_batched(const uint32_t *a, const uint32_t *b, uint32_t *ab, int n, uint32_t p,
                               size_t batch, int n_gpus);
 
-/* Same, 64-bit coefficients and any modulus (CRT path when p > 2^32). */
+/* Same, 64-bit coefficients and any modulus. */
 int ntt_poly_multiply_batched_u64(const uint64_t *a, const uint64_t *b, uint64_t *ab, int n, uint64_t p,
                                   size_t batch, int n_gpus);
 
@@ -145,7 +159,10 @@ uint32_t ntt_crt_prime(int prime_index);
  * ntt64_load_device: dst[row][i] = i < n ? src[row*src_stride + i] mod p : 0, i < len (may be in place).
  * ntt64_finalize_device: out[row*out_stride + i] = data[row*len + i] * 2^-log_total * 2^64 mod p, canonical.
  * ntt64_poly_multiply_device: the whole product on one GPU: d_out[0..2n-2] = a*b mod p.  Same results
- *   as the CRT route of ntt_poly_multiply_batched_device_u64 wherever both apply. */
+ *   as the CRT route of ntt_poly_multiply_batched_device_u64 wherever both apply.
+ * ntt64_poly_multiply_batched_device: `batch` such products in the same passes over memory (rows of a, b and the
+ *   results a_stride, b_stride, out_stride words apart); workspace from ntt64_workspace_bytes_batched, or NULL for
+ *   the library's own. */
 int ntt64_transform_device(uint64_t *d_data, uint64_t p, int log_root, int log_len, size_t inner, size_t outer,
                            int inverse, void *stream);
 int ntt64_fourstep_rows_device(uint64_t *d_slab, uint64_t p, int log_total, int log_rows, size_t cols_local, uint64_t col0,
@@ -162,6 +179,10 @@ int ntt64_finalize_device(const uint64_t *d_data, size_t len, uint64_t *d_out, s
 size_t ntt64_workspace_bytes(size_t n);
 int ntt64_poly_multiply_device(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n, uint64_t p,
                                void *workspace, size_t workspace_bytes, void *stream);
+size_t ntt64_workspace_bytes_batched(size_t n, size_t batch);
+int ntt64_poly_multiply_batched_device(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n, uint64_t p,
+                                       size_t batch, size_t a_stride, size_t b_stride, size_t out_stride, void *workspace,
+                                       size_t workspace_bytes, void *stream);
 
 /* Stand-alone transform in natural order, in place: the reference's `NTT(a, n, invert, p, 3)`
  * (main_naive.cc:96-137) including its bit-reversal (main_naive.cc:82-95) and, for invert != 0, the

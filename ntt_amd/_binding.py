@@ -19,7 +19,7 @@ c_u64p = ctypes.POINTER(ctypes.c_uint64)
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 
 EXPORTS = [
-    "ntt_init", "ntt_shutdown", "ntt_device_count", "ntt_last_error",
+    "ntt_init", "ntt_shutdown", "ntt_device_count", "ntt_last_error", "ntt_set_route_policy",
     "poly_multiply", "poly_multiply_u64", "ntt_poly_multiply_i32", "ntt_poly_multiply_u64",
     "ntt_poly_multiply_batched", "ntt_poly_multiply_batched_u64",
     "ntt_workspace_bytes", "ntt_poly_multiply_batched_device", "ntt_poly_multiply_batched_device_u64",
@@ -27,6 +27,7 @@ EXPORTS = [
     "ntt_crt_merge_device", "ntt_crt_residue_product_device", "ntt_crt_prime", "ntt_describe_plan",
     "ntt64_transform_device", "ntt64_fourstep_rows_device", "ntt64_fourstep_cols_device", "ntt64_twiddle_device", "ntt64_pointwise_device", "ntt64_load_device",
     "ntt64_finalize_device", "ntt64_workspace_bytes", "ntt64_poly_multiply_device",
+    "ntt64_workspace_bytes_batched", "ntt64_poly_multiply_batched_device",
     "ntt_transform_u64", "ntt_transform_device_u64",
     "ntt_io_read_header", "ntt_io_read_in", "ntt_io_check_out", "ntt_io_read_out", "ntt_io_write_out",
     "ntt_profile_enable", "ntt_profile_read",
@@ -86,6 +87,10 @@ class NttLibrary:
         L.ntt64_finalize_device.argtypes = [vp, sz, vp, sz, sz, sz, u64, ci, ci, vp]; L.ntt64_finalize_device.restype = ci
         L.ntt64_workspace_bytes.argtypes = [sz]; L.ntt64_workspace_bytes.restype = sz
         L.ntt64_poly_multiply_device.argtypes = [vp, vp, vp, sz, u64, vp, sz, vp]; L.ntt64_poly_multiply_device.restype = ci
+        L.ntt_set_route_policy.argtypes = [ci]; L.ntt_set_route_policy.restype = ci
+        L.ntt64_workspace_bytes_batched.argtypes = [sz, sz]; L.ntt64_workspace_bytes_batched.restype = sz
+        L.ntt64_poly_multiply_batched_device.argtypes = [vp, vp, vp, sz, u64, sz, sz, sz, sz, vp, sz, vp]
+        L.ntt64_poly_multiply_batched_device.restype = ci
         L.ntt_transform_u64.argtypes = [c_u64p, ci, ci, u64]; L.ntt_transform_u64.restype = ci
         L.ntt_transform_device_u64.argtypes = [vp, sz, sz, ci, u64, vp]; L.ntt_transform_device_u64.restype = ci
         i64 = ctypes.c_int64
@@ -108,6 +113,14 @@ class NttLibrary:
 
     def shutdown(self):
         self.lib.ntt_shutdown()
+
+    def set_route_policy(self, policy):
+        """'auto' (fastest exact route) or 'reference' (four-prime CRT wherever the reference uses it); returns the old one."""
+        names = ["auto", "reference"]
+        old = self.lib.ntt_set_route_policy(names.index(policy))
+        if old < 0:
+            raise NttError(-1, self.last_error())
+        return names[old]
 
     def describe_plan(self, n, p):
         buf = ctypes.create_string_buffer(256)

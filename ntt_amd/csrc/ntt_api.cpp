@@ -22,6 +22,7 @@
 
 #include <condition_variable>
 #include <functional>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -645,9 +646,11 @@ std::vector<Step64> plan_steps(int log_len, size_t inner, size_t outer) {
 }
 
 struct TileExtra {           // fusions of a product's first and last pass
-    const uint64_t* src = nullptr; uint64_t src_valid = 0;               // forward: raw operands, zero beyond src_valid
+    const uint64_t* src = nullptr; uint64_t src_valid = 0;               // forward: raw operands, rows zero beyond src_valid
     uint64_t* out = nullptr; uint64_t n_out = 0; uint64_t scale_word = 0; // inverse: scaled canonical output
     const uint64_t* other = nullptr;                                      // inverse local pass: pointwise product first
+    int row_shift = 63;                                                   // log2 of a product's work row (63: one product)
+    uint64_t src_stride = 0, out_stride = 0;                              // rows of the operands / results in caller memory
 };
 
 // Where the passes of one transform live and which twiddles join them: the middle axis of [outer][2^log_len][inner].
@@ -715,6 +718,9 @@ int run_step(const Plan64& pl, uint64_t* d, const Step64& s, const Axis64& ax, b
         g.tw_mask = ((uint64_t)1 << pl.log_root) - 1;
         g.q = s.q;
         g.src_valid = ex.src_valid;
+        g.row_shift = ex.row_shift;
+        g.src_stride = ex.src_stride;
+        g.out_stride = ex.out_stride;
         g.hi_shift = 63;
         g.lo_mask = ~(uint64_t)0;
         if (ax.col_bits == 0) {           // plain transform: the twiddle index is the column's position in the block, x / inner
@@ -842,29 +848,31 @@ void twiddle64(const Plan64& pl, uint64_t* d, uint64_t rows, uint64_t cols, uint
     else NTT_LAUNCH_P("k64_twiddle", (k64_twiddle<Field64>), dim3(grid_for(rows * cols)), dim3(256), st, d, rows, cols, row0, col0, row_bits, rows_bitrev, inverse, (uint64_t)1, mask, pl.fc, pl.tw);
 }
 
-// One product in the field, operands and result in caller memory, two work arrays of L words.  When the first pass of
-// the transform is a tile pass, the operand load (reduction of arbitrary words, zero padding) rides on it, the pointwise
-// product on the first pass of the inverse, and scaling, canonical reduction and the copy to `out` on its last pass.
+// `rows` products in the field at once, operands and results in caller memory, two work arrays of rows * L words.  When
+// the first pass of the transform is a tile pass, the operand load (reduction of arbitrary words, zero padding) rides on
+// it, the pointwise product on the first pass of the inverse, and scaling, canonical reduction and the copy to `out`
+// on its last pass.
 template <class F>
-int product64_row(const Plan64& pl, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int logL, uint64_t* wa, uint64_t* wb,
-                  hipStream_t st) {
+int product64_rows(const Plan64& pl, const uint64_t* a, size_t sa, const uint64_t* b, size_t sb, uint64_t* out, size_t so, size_t n,
+                   int logL, size_t rows, uint64_t* wa, uint64_t* wb, hipStream_t st) {
     const size_t L = (size_t)1 << logL;
     const uint64_t p = pl.fc.p;
     const uint64_t Linv = h_powmod((uint64_t)L % p, p - 2, p);
     const uint64_t scale = h_mulmod(Linv, pointwise_compensation(pl), p);
-    const std::vector<Step64> steps = plan_steps(logL, 1, 1);
+    const std::vector<Step64> steps = plan_steps(logL, 1, rows);
     Axis64 ax;
     ax.log_len = logL;
+    ax.outer = rows;
     int rc;
     const bool fused = steps.size() >= 2 && steps.front().kind == Step64::TILE && steps.back().kind == Step64::LOCAL;
     if (!fused) {
-        load64(pl, a, 0, n, wa, L, 1, st);
-        load64(pl, b, 0, n, wb, L, 1, st);
+        load64(pl, a, sa, n, wa, L, rows, st);
+        load64(pl, b, sb, n, wb, L, rows, st);
         if ((rc = transform64_f<F>(pl, wa, ax, false, st)) != NTT_OK) return rc;
         if ((rc = transform64_f<F>(pl, wb, ax, false, st)) != NTT_OK) return rc;
-        pointwise64(pl, wa, wb, L, st);
+        pointwise64(pl, wa, wb, rows * L, st);
         if ((rc = transform64_f<F>(pl, wa, ax, true, st)) != NTT_OK) return rc;
-        finalize64(pl, wa, L, out, 0, 2 * n - 1, 1, scale, st);
+        finalize64(pl, wa, L, out, so, 2 * n - 1, rows, scale, st);
         HIP_TRY(hipGetLastError());
         return NTT_OK;
     }
@@ -874,19 +882,30 @@ int product64_row(const Plan64& pl, const uint64_t* a, const uint64_t* b, uint64
         TileExtra first;
         first.src = side ? b : a;
         first.src_valid = n;
+        first.row_shift = logL;
+        first.src_stride = side ? sb : sa;
         for (size_t i = 0; i < steps.size(); ++i)
             if ((rc = run_step<F>(pl, w, steps[i], ax, false, i == 0 ? first : none, st)) != NTT_OK) return rc;
     }
     for (size_t i = steps.size(); i-- > 0;) {
         TileExtra ex;
         if (i + 1 == steps.size()) ex.other = wb;
-        if (i == 0) { ex.out = out; ex.n_out = 2 * n - 1; ex.scale_word = tw_word(pl, scale); }
+        if (i == 0) { ex.out = out; ex.n_out = 2 * n - 1; ex.scale_word = tw_word(pl, scale); ex.row_shift = logL; ex.out_stride = so; }
         if ((rc = run_step<F>(pl, wa, steps[i], ax, true, ex, st)) != NTT_OK) return rc;
     }
     return NTT_OK;
 }
 
-// whole products in the 64-bit field, one row after the other through one workspace
+// products that share one pass over the work arrays: as many as fit 256 MiB per array (128 at L = 2^18, one from 2^25)
+size_t field64_group_rows(int logL, size_t batch) {
+    const size_t fit = logL >= 25 ? 1 : ((size_t)1 << (25 - logL));
+    return batch < 1 ? 1 : (batch < fit ? batch : fit);
+}
+size_t field64_workspace_bytes(int logL, size_t batch) {
+    return 2 * field64_group_rows(logL, batch) * ((size_t)1 << logL) * sizeof(uint64_t);
+}
+
+// whole products in the 64-bit field, a group of rows at a time through one workspace
 int field64_product_device(Device* dev, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint64_t p, size_t batch,
                            size_t sa, size_t sb, size_t so, void* ws, size_t ws_bytes, hipStream_t st) {
     int logL = ceil_log2(2 * (uint64_t)n - 1);
@@ -894,17 +913,18 @@ int field64_product_device(Device* dev, const uint64_t* a, const uint64_t* b, ui
     Plan64* pl = nullptr;
     int rc = get_plan64(dev, p, logL, &pl);
     if (rc != NTT_OK) return rc;
-    const size_t L = (size_t)1 << logL, need = 2 * L * sizeof(uint64_t);
+    const size_t L = (size_t)1 << logL, group = field64_group_rows(logL, batch), need = field64_workspace_bytes(logL, batch);
     if (ws) {
         if (ws_bytes < need) return fail(NTT_ERR_WORKSPACE, "workspace too small");
     } else {
         if ((rc = dev->workspace_for(st, need, &ws)) != NTT_OK) return rc;
     }
     uint64_t* wa = (uint64_t*)ws;
-    uint64_t* wb = wa + L;
-    for (size_t row = 0; row < batch; ++row) {
-        rc = pl->fp ? product64_row<FieldD>(*pl, a + row * sa, b + row * sb, out + row * so, n, logL, wa, wb, st)
-                    : product64_row<Field64>(*pl, a + row * sa, b + row * sb, out + row * so, n, logL, wa, wb, st);
+    uint64_t* wb = wa + group * L;
+    for (size_t row = 0; row < batch; row += group) {
+        const size_t rows = batch - row < group ? batch - row : group;
+        rc = pl->fp ? product64_rows<FieldD>(*pl, a + row * sa, sa, b + row * sb, sb, out + row * so, so, n, logL, rows, wa, wb, st)
+                    : product64_rows<Field64>(*pl, a + row * sa, sa, b + row * sb, sb, out + row * so, so, n, logL, rows, wa, wb, st);
         if (rc != NTT_OK) return rc;
     }
     return NTT_OK;
@@ -913,7 +933,7 @@ int field64_product_device(Device* dev, const uint64_t* a, const uint64_t* b, ui
 size_t wide_crt_workspace_bytes(size_t n, uint64_t p, size_t batch) {
     const int logL = ceil_log2(2 * (uint64_t)n - 1) < 1 ? 1 : ceil_log2(2 * (uint64_t)n - 1);
     const size_t k = (size_t)wide_crt_primes_needed(n, p);
-    return 2 * ((size_t)1 << logL) * sizeof(uint64_t) + k * batch * (2 * n - 1) * sizeof(uint64_t);
+    return field64_workspace_bytes(logL, batch) + k * batch * (2 * n - 1) * sizeof(uint64_t);
 }
 
 int make_wide_crt_consts(uint64_t p, int k, WideCrtConsts* c) {
@@ -965,20 +985,28 @@ int wide_crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, u
     return NTT_OK;
 }
 
-// Which arithmetic serves (n, p):
+// Which arithmetic serves (n, p), in the order tried:
 //   32-bit direct  p < 2^31 NTT-friendly and L <= 2^18 (every case the reference's NTT_multiply covers)
+//   64-bit field in double precision   prime p <= 1.5e15 with L | p-1: the reference's large modulus among them.  Same
+//                  residues as the CRT route at about half its cost (three transforms of one 64-bit array instead of
+//                  twelve of 32-bit ones plus the merge); skipped under NTT_ROUTE_REFERENCE
 //   four-prime CRT any p with n*(p-1)^2 below the product of the primes, L <= 2^18 (the reference's route for p > 2^32)
-//   64-bit field   p < 2^60 with L | p-1: lengths and moduli beyond both of the above
+//   64-bit field   p < 2^60 with L | p-1: lengths and moduli beyond the above, integer Montgomery arithmetic
 //   wide CRT       everything else up to L = 2^32: two or three 59-bit NTT primes, Garner recombination
 enum Route { ROUTE_DIRECT32, ROUTE_CRT, ROUTE_FIELD64, ROUTE_WIDECRT, ROUTE_NONE };
 constexpr int MAX_LOG_L32 = 18;
+std::atomic<int> g_route_policy{NTT_ROUTE_AUTO};
 
 Route choose_route(uint64_t p, size_t n, std::string* why) {
     int logL = ceil_log2(2 * (uint64_t)n - 1);
     if (logL < 1) logL = 1;
     if (logL <= MAX_LOG_L32 && direct_path_ok(p, logL)) return ROUTE_DIRECT32;
-    if (logL <= MAX_LOG_L32 && n < (1u << 30) && crt_bound_ok((int)n, p)) return ROUTE_CRT;
     std::string w64;
+    const bool crt = logL <= MAX_LOG_L32 && n < (1u << 30) && crt_bound_ok((int)n, p);
+    if (crt && g_route_policy.load() == NTT_ROUTE_AUTO && fieldd_allowed() && p < (1ull << 60) && (double)p <= FIELDD_MAX_P &&
+        modulus64_ok(p, logL, &w64))
+        return ROUTE_FIELD64;
+    if (crt) return ROUTE_CRT;
     if (modulus64_ok(p, logL, &w64)) return ROUTE_FIELD64;
     if (p >= 2 && logL <= 32 && wide_crt_primes_needed(n, p) != 0) return ROUTE_WIDECRT;
     if (why) *why = "no exact route for this modulus and length: the four-prime CRT needs n*(p-1)^2 < 2^118.9 and length <= 2^18; "
@@ -1420,7 +1448,7 @@ size_t ntt_workspace_bytes(int n, uint64_t p, size_t batch) {
     switch (choose_route(p, (size_t)n, nullptr)) {
         case ROUTE_DIRECT32: return pipeline_workspace_bytes(logL, batch);
         case ROUTE_CRT: return crt_workspace_bytes(logL, batch);
-        case ROUTE_FIELD64: return 2 * ((size_t)1 << logL) * sizeof(uint64_t);
+        case ROUTE_FIELD64: return field64_workspace_bytes(logL, batch);
         case ROUTE_WIDECRT: return wide_crt_workspace_bytes((size_t)n, p, batch);
         default: return 0;
     }
@@ -1737,6 +1765,35 @@ int ntt64_poly_multiply_device(const uint64_t* d_a, const uint64_t* d_b, uint64_
     Device* dev = nullptr;
     if ((rc = current_device(&dev)) != NTT_OK) return rc;
     return field64_product_device(dev, d_a, d_b, d_out, n, p, 1, n, n, 2 * n - 1, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ntt_set_route_policy(int policy) {
+    if (policy != NTT_ROUTE_AUTO && policy != NTT_ROUTE_REFERENCE) { fail(NTT_ERR_ARG, "unknown route policy"); return -1; }
+    return g_route_policy.exchange(policy);
+}
+
+size_t ntt64_workspace_bytes_batched(size_t n, size_t batch) {
+    NTT_API_LOCK;
+    if (n < 1) return 0;
+    const int logL = ceil_log2(2 * (uint64_t)n - 1) < 1 ? 1 : ceil_log2(2 * (uint64_t)n - 1);
+    return field64_workspace_bytes(logL, batch);
+}
+
+int ntt64_poly_multiply_batched_device(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n, uint64_t p, size_t batch,
+                                       size_t a_stride, size_t b_stride, size_t out_stride, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    NTT_API_LOCK;
+    if (batch == 0) return NTT_OK;
+    if (!d_a || !d_b || !d_out) return fail(NTT_ERR_ARG, "null pointer");
+    if (n < 1 || n > ((size_t)1 << 34)) return fail(NTT_ERR_ARG, "n out of range");
+    if (a_stride < n || b_stride < n || out_stride < 2 * n - 1) return fail(NTT_ERR_ARG, "row strides shorter than the rows");
+    if (batch > ((size_t)1 << 24)) return fail(NTT_ERR_ARG, "batch too large");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    return field64_product_device(dev, d_a, d_b, d_out, n, p, batch, a_stride, b_stride, out_stride, workspace, workspace_bytes,
+                                  (hipStream_t)stream);
 }
 
 // ---- stand-alone transforms in natural order (the reference's NTT(), main_naive.cc:96-137) ----

@@ -62,7 +62,11 @@ struct Pass64 {
     uint64_t tw_mask;       // table root order - 1
     int q;                  // log2 rows
     uint64_t tiles_per_block;   // k64_tile: columns / W
-    uint64_t src_valid;     // first pass of a product reading caller data: elements of the source beyond this index are zero
+    uint64_t src_valid;     // first pass of a product reading caller data: elements of a source row beyond this index are zero
+    // first / last pass of a batch of products: element e of the work array belongs to product e >> row_shift, position
+    // e & (2^row_shift - 1); the operands' rows are src_stride and the results' rows out_stride elements apart
+    int row_shift;
+    uint64_t src_stride, out_stride;
 };
 
 NTT_HD uint64_t pass_jq(const Pass64& g, uint64_t x) {
@@ -151,10 +155,10 @@ NTT_HD uint64_t bitrev64(uint64_t x, int bits) {
 //   thread t: column x = t % W, group grp = t / W (grp < R/16).
 //   round over blocks of 2^b rows (b = q, q-4, ... > 4): rows blk*2^b + j + m*2^(b-4), m < 16, (blk, j) from grp
 //   last round (blocks of 2^ql <= 16 rows): rows 16 grp + i, i < 16.
-// SRC_RAW (forward only): the first round reads caller data (any 64-bit words, zero beyond g.src_valid elements)
-//   from `src` instead of `data`.
-// FINAL (inverse only): the last round multiplies by `scale`, reduces to [0,p) and writes the elements below
-//   n_out to `out` instead of `data`.
+// SRC_RAW (forward only): the first round reads caller data (any 64-bit words, rows of g.src_valid elements, zero
+//   beyond) from `src` instead of `data`.
+// FINAL (inverse only): the last round multiplies by `scale`, reduces to [0,p) and writes the first n_out elements of
+//   every row to `out` instead of `data`.
 // ---------------------------------------------------------------------------
 template <class F, bool INVERSE, bool SRC_RAW, bool FINAL>
 __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint64_t* src, uint64_t* out, uint64_t n_out,
@@ -177,6 +181,7 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
     const uint64_t origin = blk_g * g.block_stride + col;       // element offset of row 0 of this column
     const uint64_t jq = pass_jq(g, col);
     const int ql = ((q - 1) & 3) + 1;                           // levels of the last (smallest) round, 1..4
+    const uint64_t row_mask = ((uint64_t)1 << g.row_shift) - 1;
     V v[16];
 
     // Pass twiddles of the 16 rows 16*grp + i that a thread holds in the last forward / first inverse round: row r holds
@@ -214,8 +219,12 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
                 const uint64_t dstep = (uint64_t)sub * step;
 #pragma unroll
                 for (int m = 0; m < 16; ++m, idx += dstep) {
-                    if (SRC_RAW) v[m] = idx < g.src_valid ? f.from_raw(src[idx]) : V(0);
-                    else v[m] = f.from_mem(data[idx]);
+                    if (SRC_RAW) {
+                        const uint64_t pos = idx & row_mask;
+                        v[m] = pos < g.src_valid ? f.from_raw(src[(idx >> g.row_shift) * g.src_stride + pos]) : V(0);
+                    } else {
+                        v[m] = f.from_mem(data[idx]);
+                    }
                 }
             } else {
 #pragma unroll
@@ -270,7 +279,8 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
 #pragma unroll
                 for (int m = 0; m < 16; ++m, o += dstep) {
                     if (FINAL) {
-                        if (o < n_out) out[o] = f.canon(f.twiddled(v[m], scale));
+                        const uint64_t pos = o & row_mask;
+                        if (pos < n_out) out[(o >> g.row_shift) * g.out_stride + pos] = f.canon(f.twiddled(v[m], scale));
                     } else {
                         data[o] = f.to_mem(v[m]);
                     }

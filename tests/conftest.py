@@ -24,6 +24,20 @@ def reference():
     return Reference()
 
 
+_product_libraries = []   # every product library a fixture has loaded (the twin and the GPU library are separate images)
+
+
+@pytest.fixture(params=["auto", "reference"])
+def route(request):
+    """Runs the test once per route policy: the fastest route for large NTT-friendly moduli (direct 64-bit field) and
+    the reference's own (four-prime CRT).  Request it after the library fixture."""
+    for lib in _product_libraries:
+        lib.set_route_policy(request.param)
+    yield request.param
+    for lib in _product_libraries:
+        lib.set_route_policy("auto")
+
+
 @pytest.fixture(scope="session")
 def twin():
     """CPU twin of the GPU library (same sources over a HIP stand-in); test-only."""
@@ -31,7 +45,9 @@ def twin():
     path = os.path.join(ROOT, "tests", "cpu_twin", "libnttamd_cputwin.so")
     if not os.path.exists(path):
         pytest.skip("CPU twin not built (make -C tests/cpu_twin)")
-    return NttLibrary(path)
+    lib = NttLibrary(path)
+    _product_libraries.append(lib)
+    return lib
 
 
 @pytest.fixture(scope="session")
@@ -42,4 +58,5 @@ def gpu_lib():
     from ntt_amd._binding import load_product_library
     lib = load_product_library()
     lib.init(0)
+    _product_libraries.append(lib)
     return lib

@@ -20,7 +20,7 @@ def test_direct_path_all_size_classes(twin, oracle, p):
         assert np.array_equal(twin.multiply_u64(a, b, p), oracle.ntt_multiply(a, b, p)), n
 
 
-def test_golden_vectors(twin):
+def test_golden_vectors(twin, route):
     for name, n, p, a, b, out in iter_golden():
         assert np.array_equal(twin.multiply_u64(a, b, p), out), name
 
@@ -32,7 +32,7 @@ def test_extreme_values_exercise_lazy_bounds(twin, oracle):
             assert np.array_equal(twin.multiply_u64(a, a, p), oracle.ntt_multiply(a, a, p)), (p, n)
 
 
-def test_crt_path(twin, oracle):
+def test_crt_path(twin, oracle, route):
     rng = np.random.default_rng(4)
     for n in (1, 4, 1000, 4096, 8192, 131072):
         a = rng.integers(0, BIGP, n, dtype=np.uint64); b = rng.integers(0, BIGP, n, dtype=np.uint64)
@@ -60,7 +60,7 @@ def test_non_power_of_two_lengths(twin, oracle):
         assert np.array_equal(twin.multiply_u64(a, b, p), oracle.ntt_multiply(az, bz, p)[:2 * n - 1]), n
 
 
-def test_batched_and_i32_entry_points(twin, oracle):
+def test_batched_and_i32_entry_points(twin, oracle, route):
     p = 998244353
     rng = np.random.default_rng(8)
     for n, batch in ((4096, 5), (1024, 9), (16384, 3)):
@@ -87,7 +87,12 @@ def test_error_reporting(twin):
         twin.multiply_batched(np.ones((2, 8), dtype=np.uint32), np.ones((2, 8), dtype=np.uint32), 1000000007)
     assert twin.describe_plan(131072, 998244353) == "k_fwd_strided,k_core_mul,k_inv_strided"
     assert twin.describe_plan(4096, 998244353) == "k_fused8192"
+    twin.set_route_policy("reference")
     assert twin.describe_plan(4, BIGP).endswith("k_crt_merge")
+    assert twin.lib.ntt_workspace_bytes(131072, BIGP, 3) == 2 * 3 * (1 << 18) * 4 + 4 * 3 * (1 << 18) * 4
+    twin.set_route_policy("auto")
+    assert twin.describe_plan(4, BIGP).startswith("k64_")
+    assert twin.lib.ntt_workspace_bytes(1024, BIGP, 3) == twin.lib.ntt64_workspace_bytes_batched(1024, 3) == 2 * 3 * 2048 * 8
     assert twin.lib.ntt_workspace_bytes(131072, 998244353, 4) == 2 * 4 * (1 << 18) * 4
 
 
@@ -113,6 +118,36 @@ def test_64bit_field_product(twin, oracle):
             assert np.array_equal(_twin_mul64(twin, a, b, p), want), (p, n)
     a = rng.integers(0, 2**64, 300, dtype=np.uint64); b = rng.integers(0, 2**64, 300, dtype=np.uint64)
     assert np.array_equal(_twin_mul64(twin, a, b, BIGP), oracle.schoolbook_u64(a % BIGP, b % BIGP, BIGP))
+
+
+def check_batched_field_product(lib, oracle, to_dev, from_dev, stream, p, n, batch, pad=(3, 0, 5)):
+    """ntt64_poly_multiply_batched_device against the oracle: rows with strides longer than the rows, unreduced inputs."""
+    rng = np.random.default_rng(n * 31 + batch)
+    sa, sb, so = n + pad[0], n + pad[1], 2 * n - 1 + pad[2]
+    a = rng.integers(0, 2**64, (batch, sa), dtype=np.uint64); b = rng.integers(0, p, (batch, sb), dtype=np.uint64)
+    ta, tb = to_dev(a), to_dev(b)
+    out = to_dev(np.full((batch, so), 7, dtype=np.uint64))
+    ws = lib.lib.ntt64_workspace_bytes_batched(n, batch)
+    assert ws >= 16 * (2 * n - 1)
+    lib.check(lib.lib.ntt64_poly_multiply_batched_device(ta.data_ptr(), tb.data_ptr(), out.data_ptr(), n, p, batch, sa, sb, so,
+                                                         None, 0, stream))
+    got = from_dev(out).reshape(batch, so)
+    m = 1 << (n - 1).bit_length() if n > 1 else 1
+    for r in range(batch):
+        az = np.zeros(m, dtype=np.uint64); bz = np.zeros(m, dtype=np.uint64)
+        az[:n] = a[r, :n] % np.uint64(p); bz[:n] = b[r, :n]
+        want = oracle.poly_multiply_u64(az, bz, p)[:2 * n - 1]
+        assert np.array_equal(got[r, :2 * n - 1], want), (p, n, r)
+        assert (got[r, 2 * n - 1:] == 7).all(), "padding between result rows was written"
+
+
+def test_64bit_field_batched_products(twin, oracle):
+    import torch
+    to_dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64).copy())
+    from_dev = lambda t: t.numpy().view(np.uint64).copy()
+    for p, n, batch in ((BIGP, 1, 3), (BIGP, 5, 4), (BIGP, 100, 3), (998244353, 2048, 5), (BIGP, 4096, 2), (BIGP, 5000, 3),
+                        (BIGP, 65536, 3), (998244353, 40000, 2)):
+        check_batched_field_product(twin, oracle, to_dev, from_dev, None, p, n, batch)
 
 
 def test_64bit_field_rejects_unfriendly_moduli(twin):
@@ -156,8 +191,12 @@ def test_route_selection_beyond_the_reference_range(twin):
         e = np.zeros(n, dtype=np.uint64); e[5] = 1
         got = twin.multiply_u64(a, e, p)
         assert np.array_equal(got[5:5 + n], a) and not got[:5].any() and not got[5 + n:].any()
+    assert twin.describe_plan(1 << 17, BIGP).startswith("k64_")
+    assert twin.set_route_policy("reference") == "auto"
     assert twin.describe_plan(1 << 17, BIGP).endswith("k_crt_merge")
-    assert twin.describe_plan(1 << 18, BIGP).startswith("k64_")
+    assert twin.describe_plan(1 << 18, BIGP).startswith("k64_")       # past the CRT route's length limit either way
+    assert twin.set_route_policy("auto") == "reference"
+    assert twin.lib.ntt_set_route_policy(7) == -1 and "route policy" in twin.last_error()
     assert twin.describe_plan(1 << 19, 998244353).startswith("k64_")
 
 
@@ -315,10 +354,13 @@ p, n, batch = 998244353, 2048, 43          # 1.4 MB of rows against a 1 MB limit
 a = rng.integers(0, p, (batch, n), dtype=np.uint32); b = rng.integers(0, p, (batch, n), dtype=np.uint32)
 got = lib.multiply_batched(a, b, p, 1)
 ok = all(np.array_equal(got[r].astype(np.uint64), orc.ntt_multiply(a[r], b[r], p)) for r in range(batch))
-P, n2, batch2 = 1337006139375617, 1024, 21  # 64-bit rows through the four-prime route, workspace per staging set
+P, n2, batch2 = 1337006139375617, 1024, 21  # 64-bit rows through both large-modulus routes, workspace per staging set
 A = rng.integers(0, P, (batch2, n2), dtype=np.uint64); B = rng.integers(0, P, (batch2, n2), dtype=np.uint64)
-got2 = lib.multiply_batched_u64(A, B, P, 1)
-ok2 = all(np.array_equal(got2[r], orc.crt_ntt_multiply(A[r], B[r], P)) for r in range(batch2))
+ok2 = True
+for policy in ("auto", "reference"):
+    lib.set_route_policy(policy)
+    got2 = lib.multiply_batched_u64(A, B, P, 1)
+    ok2 = ok2 and all(np.array_equal(got2[r], orc.crt_ntt_multiply(A[r], B[r], P)) for r in range(batch2))
 one = lib.multiply_batched(a[:1], b[:1], p, 1)   # small call afterwards: single-buffer path again
 print("RESULT", ok, ok2, bool(np.array_equal(one[0], got[0])))
 '''

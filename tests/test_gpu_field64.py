@@ -48,6 +48,29 @@ def test_extreme_and_unreduced_inputs(gpu_lib, oracle):
     assert np.array_equal(gpu_mul64(gpu_lib, a, b, BIGP), oracle.schoolbook_u64(a % BIGP, b % BIGP, BIGP))
 
 
+@pytest.mark.parametrize("p,n,batch", [(BIGP, 1, 3), (BIGP, 100, 7), (998244353, 2048, 33), (BIGP, 4096, 16), (BIGP, 5000, 3),
+                                       (BIGP, 65536, 5), (998244353, 40000, 2), (BIGP, 131072, 9), (BIGP, 131072, 130)])
+def test_batched_products_in_the_field(gpu_lib, oracle, p, n, batch):
+    import torch
+    from test_cpu_twin import check_batched_field_product
+    to_dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64).copy()).cuda()
+    from_dev = lambda t: t.cpu().numpy().view(np.uint64).copy()
+    if batch > 100:   # more rows than one group of the workspace: every row against a few distinct operands
+        rng = np.random.default_rng(5)
+        a0 = rng.integers(0, p, (3, n), dtype=np.uint64); b0 = rng.integers(0, p, (3, n), dtype=np.uint64)
+        want = [oracle.poly_multiply_u64(a0[i], b0[i], p) for i in range(3)]
+        idx = np.arange(batch) % 3
+        out = torch.zeros((batch, 2 * n - 1), dtype=torch.int64, device="cuda")
+        ta, tb = to_dev(a0[idx]), to_dev(b0[idx])
+        gpu_lib.check(gpu_lib.lib.ntt64_poly_multiply_batched_device(ta.data_ptr(), tb.data_ptr(), out.data_ptr(), n, p, batch, n, n,
+                                                                     2 * n - 1, None, 0, torch.cuda.current_stream().cuda_stream))
+        got = from_dev(out).reshape(batch, 2 * n - 1)
+        for r in range(batch):
+            assert np.array_equal(got[r], want[idx[r]]), r
+        return
+    check_batched_field_product(gpu_lib, oracle, to_dev, from_dev, torch.cuda.current_stream().cuda_stream, p, n, batch)
+
+
 @pytest.mark.parametrize("n", [7, 4096, 30000, 131072])
 def test_explicit_fourstep_single_gpu(gpu_lib, oracle, n):
     import torch

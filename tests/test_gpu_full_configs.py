@@ -75,7 +75,7 @@ def test_65536_products_of_n_4096(gpu_lib, oracle, p):
         assert torch.equal(out_s[lo:lo + 8192].to(torch.int64), want)
 
 
-def test_64_large_modulus_products_every_row_against_the_oracle(gpu_lib, oracle):
+def test_64_large_modulus_products_every_row_against_the_oracle(gpu_lib, oracle, route):
     import torch
     L = gpu_lib.lib
     n, batch, p = 131072, 64, BIGP

@@ -16,7 +16,7 @@ def expected(oracle, a, b, p):
     return oracle.schoolbook_u64(a, b, p)
 
 
-def test_random_shapes_u64_device(gpu_lib, oracle):
+def test_random_shapes_u64_device(gpu_lib, oracle, route):
     import torch
     rng = np.random.default_rng(20240607)
     L = gpu_lib.lib

@@ -51,7 +51,7 @@ def test_extreme_values(gpu_lib, oracle, p, n):
 
 
 @pytest.mark.parametrize("n", [1, 4, 1000, 4096, 8192, 131072])
-def test_crt_path_matches_oracle(gpu_lib, oracle, n):
+def test_crt_path_matches_oracle(gpu_lib, oracle, n, route):
     rng = np.random.default_rng(n + 99)
     a, b = rand(rng, BIGP, n), rand(rng, BIGP, n)
     if n & (n - 1) == 0:
@@ -61,7 +61,7 @@ def test_crt_path_matches_oracle(gpu_lib, oracle, n):
     assert np.array_equal(gpu_lib.multiply_u64(a, b, BIGP), want)
 
 
-def test_crt_path_extreme_values(gpu_lib, oracle):
+def test_crt_path_extreme_values(gpu_lib, oracle, route):
     n = 131072
     a = np.full(n, BIGP - 1, dtype=np.uint64)
     assert np.array_equal(gpu_lib.multiply_u64(a, a, BIGP), oracle.crt_ntt_multiply(a, a, BIGP))
@@ -95,7 +95,7 @@ def test_batched_rows_are_independent_products(gpu_lib, oracle, n, batch):
         assert np.array_equal(got[r].astype(np.uint64), oracle.ntt_multiply(a[r], b[r], p)), r
 
 
-def test_batched_u64_crt(gpu_lib, oracle):
+def test_batched_u64_crt(gpu_lib, oracle, route):
     n, batch = 4096, 5
     rng = np.random.default_rng(11)
     a, b = rand(rng, BIGP, (batch, n)), rand(rng, BIGP, (batch, n))
@@ -104,7 +104,7 @@ def test_batched_u64_crt(gpu_lib, oracle):
         assert np.array_equal(got[r], oracle.crt_ntt_multiply(a[r], b[r], BIGP)), r
 
 
-def test_golden_files(gpu_lib):
+def test_golden_files(gpu_lib, route):
     """Every committed golden vector: the reference's own data files (nttdata/0-3, filetest/0-3)
     and outputs of the compiled reference on seeded inputs (p = 998244353, CRT path, CRT primes)."""
     from golden_util import iter_golden

@@ -1,10 +1,11 @@
 """Per-kernel times of the four-prime CRT product (n = 2^17, p = 1337006139375617) in steady state.
-usage: python tools/profile_config4.py [batch]"""
+usage: python tools/profile_config4.py [batch] [auto|reference]   (route policy: direct 64-bit field / four-prime CRT)"""
 import ctypes, sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, torch
 from ntt_amd._binding import load_product_library
 lib = load_product_library(); lib.init(0)
+lib.set_route_policy(sys.argv[2] if len(sys.argv) > 2 else "auto")
 L = lib.lib
 B, n, p = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), 131072, 1337006139375617
 rng = np.random.default_rng(1)
@@ -18,6 +19,12 @@ import time
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.15:   # past the clock transient
     step(); torch.cuda.synchronize()
+print("kernels:", lib.describe_plan(n, p))
+t0 = time.perf_counter()
+for _ in range(20): step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 20
+print(f"{dt*1e3:.3f} ms per batch of {B} -> {B/dt:.0f} products/s")
 L.ntt_profile_enable(1)
 for _ in range(5): step()
 torch.cuda.synchronize()
