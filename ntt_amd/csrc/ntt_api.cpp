@@ -848,6 +848,13 @@ void twiddle64(const Plan64& pl, uint64_t* d, uint64_t rows, uint64_t cols, uint
     else NTT_LAUNCH_P("k64_twiddle", (k64_twiddle<Field64>), dim3(grid_for(rows * cols)), dim3(256), st, d, rows, cols, row0, col0, row_bits, rows_bitrev, inverse, (uint64_t)1, mask, pl.fc, pl.tw);
 }
 
+// NTT_CORE64=off keeps the last forward passes, the pointwise product and the first inverse pass as separate kernels
+// (A/B measurements)
+bool fused_core_allowed() {
+    static const bool v = [] { const char* e = getenv("NTT_CORE64"); return !(e && strcmp(e, "off") == 0); }();
+    return v;
+}
+
 // `rows` products in the field at once, operands and results in caller memory, two work arrays of rows * L words.  When
 // the first pass of the transform is a tile pass, the operand load (reduction of arbitrary words, zero padding) rides on
 // it, the pointwise product on the first pass of the inverse, and scaling, canonical reduction and the copy to `out`
@@ -877,6 +884,10 @@ int product64_rows(const Plan64& pl, const uint64_t* a, size_t sa, const uint64_
         return NTT_OK;
     }
     const TileExtra none;
+    // transforms that end in full chunks: the last forward pass of both operands, the pointwise product and the first
+    // inverse pass are one kernel
+    const bool core = steps.back().q == LOCAL64_LOG && fused_core_allowed();
+    const size_t n_outer = core ? steps.size() - 1 : steps.size();
     for (int side = 0; side < 2; ++side) {
         uint64_t* w = side ? wb : wa;
         TileExtra first;
@@ -884,10 +895,16 @@ int product64_rows(const Plan64& pl, const uint64_t* a, size_t sa, const uint64_
         first.src_valid = n;
         first.row_shift = logL;
         first.src_stride = side ? sb : sa;
-        for (size_t i = 0; i < steps.size(); ++i)
+        for (size_t i = 0; i < n_outer; ++i)
             if ((rc = run_step<F>(pl, w, steps[i], ax, false, i == 0 ? first : none, st)) != NTT_OK) return rc;
     }
-    for (size_t i = steps.size(); i-- > 0;) {
+    if (core) {
+        const uint64_t n_chunks = ((uint64_t)rows << logL) >> LOCAL64_LOG;
+        const unsigned grid = (unsigned)(n_chunks < (1u << 20) ? n_chunks : (1u << 20));
+        NTT_LAUNCH_P("k64_core_mul", (k64_core_mul<F>), dim3(grid), dim3(LOCAL64_T), st, wa, (const uint64_t*)wb, n_chunks, consts_of<F>(pl), pl.rt);
+        HIP_TRY(hipGetLastError());
+    }
+    for (size_t i = n_outer; i-- > 0;) {
         TileExtra ex;
         if (i + 1 == steps.size()) ex.other = wb;
         if (i == 0) { ex.out = out; ex.n_out = 2 * n - 1; ex.scale_word = tw_word(pl, scale); ex.row_shift = logL; ex.out_stride = so; }

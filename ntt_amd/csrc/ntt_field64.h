@@ -77,6 +77,20 @@ struct Field64 {
         x = xr + t;
         y = xr - t + B;
     }
+    // Trivial butterflies next to a multiply.  dif1_lazy: inputs in [0,2p), outputs in [0,4p) -- good for mulw (any word
+    // below 2^64 / 2), to_mem and mulpw, not for another butterfly (settle first).  dit1_lazy: inputs in [0,2p) (what mulw
+    // and from_mem deliver), outputs in [0,4p) like dit1.
+    NTT_HD void dif1_lazy(uint64_t& u, uint64_t& v) const {
+        const uint64_t s = u + v;
+        v = u - v + B;
+        u = s;
+    }
+    NTT_HD void dit1_lazy(uint64_t& x, uint64_t& y) const {
+        const uint64_t s = x + y;
+        y = x - y + B;
+        x = s;
+    }
+    NTT_HD uint64_t settle(uint64_t x) const { return csub(x, B); }          // [0,4p) -> [0,2p)
     NTT_HD uint64_t canon4(uint64_t x) const { return csub(csub(x, B), p); }  // [0,4p) -> [0,p)
     // any 64-bit x -> x mod p in [0,p):  redc(x * R2) = x*R, redc(that) = x
     NTT_HD uint64_t reduce(uint64_t x, uint64_t r2) const {
@@ -105,6 +119,10 @@ struct Field64 {
 //   reduce(x)    needs |x| < 2^52; returns |r| <= p/2 + 1
 //   dif          inputs |.| <= 1.25 p -> sum reduced (<= p/2), difference (<= 2.5 p) multiplied (<= 1.25 p)
 //   dit          x reduced first, y <= 2.5 p multiplied; outputs <= 1.75 p
+//   dif1_lazy    (trivial butterfly whose outputs go into a table-twiddle multiply, a store or the pointwise product, all
+//                of which reduce) inputs <= 1.25 p -> outputs <= 2.5 p, unreduced; `settle` before any other use
+//   dit1_lazy    (trivial butterfly fed by multiplies or loads) inputs <= 1.25 p -> outputs <= 2.5 p, which the next
+//                level (reduce / multiply by a fixed root <= p/2), the twiddle of the next round and the stores accept
 // Memory format: reduced value + p, an unsigned word in [p/2, 3p/2] (below 2^52, so the conversion in both
 // directions is one addition of a constant and one bit operation on the high word).
 // ---------------------------------------------------------------------------------------------
@@ -152,6 +170,17 @@ struct FieldD {
         a = reduce(s);
         b = reduce(d);
     }
+    NTT_HD void dif1_lazy(double& a, double& b) const {
+        const double s = a + b, d = a - b;
+        a = s;
+        b = d;
+    }
+    NTT_HD void dit1_lazy(double& x, double& y) const {
+        const double s = x + y, d = x - y;
+        x = s;
+        y = d;
+    }
+    NTT_HD double settle(double x) const { return reduce(x); }
     NTT_HD void dit(double& x, double& y, double w) const {
         const double xr = reduce(x), t = mulw(y, w);
         x = xr + t;

@@ -69,6 +69,18 @@ struct Pass64 {
     uint64_t src_stride, out_stride;
 };
 
+// timing experiments only: -DNTT_ABLATE64_MATH compiles the arithmetic out of k64_tile and k64_local (wrong results), which
+// leaves the memory floor of their access patterns
+// compiler-only barrier: keeps the loads of a later phase from being hoisted over the arithmetic of an earlier one (the
+// registers they would occupy cost more in occupancy than the early issue gains)
+#define NTT_FENCE64() asm volatile("" ::: "memory")
+
+#ifdef NTT_ABLATE64_MATH
+#define NTT_MATH64(...)
+#else
+#define NTT_MATH64(...) __VA_ARGS__
+#endif
+
 NTT_HD uint64_t pass_jq(const Pass64& g, uint64_t x) {
     const uint64_t lo = g.inner_div ? x / g.inner_div : x >> g.lo_shift;
     return ((x >> g.hi_shift) << g.hi_lshift) + (lo & g.lo_mask) + g.jq_off;
@@ -78,7 +90,9 @@ NTT_HD uint64_t pass_jq(const Pass64& g, uint64_t x) {
 // register transforms on 2^Q consecutive entries of a 16-entry array, entries OFF .. OFF + 2^Q - 1
 // (fixed roots w16^e from the field constants; DIF: natural in, bit-reversed out; DIT: the mirror)
 // ---------------------------------------------------------------------------
-template <class F, int Q, int OFF>
+// LAZY: the level of trivial butterflies next to the multiplies that follow (forward: the last level) or precede
+// (inverse: the first level) the transform does not reduce its results (F::dif1_lazy / F::dit1_lazy state the ranges).
+template <class F, int Q, int OFF, bool LAZY = false>
 NTT_HD void dif_sub(typename F::V (&x)[16], const F& f, const typename F::W (&root)[8]) {
     constexpr int N = 1 << Q;
     static_for<0, Q>([&](auto S) {
@@ -88,13 +102,14 @@ NTT_HD void dif_sub(typename F::V (&x)[16], const F& f, const typename F::W (&ro
             constexpr int i = decltype(I)::value;
             if constexpr ((i & h) == 0) {
                 constexpr int e = ((i & (h - 1)) << s) << (4 - Q);
-                if constexpr (e == 0) f.dif1(x[OFF + i], x[OFF + i + h]);
+                if constexpr (e == 0 && LAZY && h == 1) f.dif1_lazy(x[OFF + i], x[OFF + i + h]);
+                else if constexpr (e == 0) f.dif1(x[OFF + i], x[OFF + i + h]);
                 else f.dif(x[OFF + i], x[OFF + i + h], root[e]);
             }
         });
     });
 }
-template <class F, int Q, int OFF>
+template <class F, int Q, int OFF, bool LAZY = false>
 NTT_HD void dit_sub(typename F::V (&x)[16], const F& f, const typename F::W (&root)[8]) {
     constexpr int N = 1 << Q;
     static_for<0, Q>([&](auto S) {
@@ -104,37 +119,38 @@ NTT_HD void dit_sub(typename F::V (&x)[16], const F& f, const typename F::W (&ro
             constexpr int i = decltype(I)::value;
             if constexpr ((i & h) == 0) {
                 constexpr int e = ((i & (h - 1)) << s) << (4 - Q);
-                if constexpr (e == 0) f.dit1(x[OFF + i], x[OFF + i + h]);
+                if constexpr (e == 0 && LAZY && h == 1) f.dit1_lazy(x[OFF + i], x[OFF + i + h]);
+                else if constexpr (e == 0) f.dit1(x[OFF + i], x[OFF + i + h]);
                 else f.dit(x[OFF + i], x[OFF + i + h], root[e]);
             }
         });
     });
 }
 // the 16 entries as 16 >> Q independent blocks of 2^Q
-template <class F, int Q>
+template <class F, int Q, bool LAZY = false>
 NTT_HD void dif_blocks(typename F::V (&x)[16], const F& f, const typename F::W (&root)[8]) {
-    static_for<0, (16 >> Q)>([&](auto Bk) { dif_sub<F, Q, (decltype(Bk)::value << Q)>(x, f, root); });
+    static_for<0, (16 >> Q)>([&](auto Bk) { dif_sub<F, Q, (decltype(Bk)::value << Q), LAZY>(x, f, root); });
 }
-template <class F, int Q>
+template <class F, int Q, bool LAZY = false>
 NTT_HD void dit_blocks(typename F::V (&x)[16], const F& f, const typename F::W (&root)[8]) {
-    static_for<0, (16 >> Q)>([&](auto Bk) { dit_sub<F, Q, (decltype(Bk)::value << Q)>(x, f, root); });
+    static_for<0, (16 >> Q)>([&](auto Bk) { dit_sub<F, Q, (decltype(Bk)::value << Q), LAZY>(x, f, root); });
 }
-template <class F>
+template <class F, bool LAZY = false>
 NTT_HD void dif_blocks_rt(int q, typename F::V (&x)[16], const F& f, const typename F::W (&root)[8]) {
     switch (q) {
-        case 1: dif_blocks<F, 1>(x, f, root); break;
-        case 2: dif_blocks<F, 2>(x, f, root); break;
-        case 3: dif_blocks<F, 3>(x, f, root); break;
-        default: dif_blocks<F, 4>(x, f, root); break;
+        case 1: dif_blocks<F, 1, LAZY>(x, f, root); break;
+        case 2: dif_blocks<F, 2, LAZY>(x, f, root); break;
+        case 3: dif_blocks<F, 3, LAZY>(x, f, root); break;
+        default: dif_blocks<F, 4, LAZY>(x, f, root); break;
     }
 }
-template <class F>
+template <class F, bool LAZY = false>
 NTT_HD void dit_blocks_rt(int q, typename F::V (&x)[16], const F& f, const typename F::W (&root)[8]) {
     switch (q) {
-        case 1: dit_blocks<F, 1>(x, f, root); break;
-        case 2: dit_blocks<F, 2>(x, f, root); break;
-        case 3: dit_blocks<F, 3>(x, f, root); break;
-        default: dit_blocks<F, 4>(x, f, root); break;
+        case 1: dit_blocks<F, 1, LAZY>(x, f, root); break;
+        case 2: dit_blocks<F, 2, LAZY>(x, f, root); break;
+        case 3: dit_blocks<F, 3, LAZY>(x, f, root); break;
+        default: dit_blocks<F, 4, LAZY>(x, f, root); break;
     }
 }
 
@@ -230,10 +246,10 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
 #pragma unroll
                 for (int m = 0; m < 16; ++m) v[m] = lds[((row0 + m * sub) << logW) + x];
             }
-            dif_blocks<F, 4>(v, f, rF);
+            NTT_MATH64(dif_blocks<F, 4, true>(v, f, rF); v[0] = f.settle(v[0]));
             const uint64_t* T = rt.f[b] + ((size_t)j << 4);
 #pragma unroll
-            for (int pos = 1; pos < 16; ++pos) v[pos] = f.twiddled(v[pos], f.tw_from_mem(T[pos]));
+            for (int pos = 1; pos < 16; ++pos) NTT_MATH64(v[pos] = f.twiddled(v[pos], f.tw_from_mem(T[pos])));
 #pragma unroll
             for (int m = 0; m < 16; ++m) lds[((row0 + m * sub) << logW) + x] = v[m];
             __syncthreads();
@@ -242,19 +258,20 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
         // last round: rows 16*grp + i, blocks of 2^ql rows; then the pass twiddle and the store
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = lds[(((grp << 4) + i) << logW) + x];
-        dif_blocks_rt<F>(ql, v, f, rF);
+        NTT_MATH64(dif_blocks_rt<F>(ql, v, f, rF));
         uint64_t idx = origin + (uint64_t)(grp << 4) * step;
         static_for<0, 16>([&](auto I) {
             constexpr int i = decltype(I)::value;
-            data[idx + (uint64_t)i * step] = f.to_mem(f.twiddled(v[i], pass_twiddle(I)));
+            NTT_MATH64(v[i] = f.twiddled(v[i], pass_twiddle(I)));
+            data[idx + (uint64_t)i * step] = f.to_mem(v[i]);
         });
     } else {
         // first round of the inverse = mirror of the last forward round
         uint64_t idx = origin + (uint64_t)(grp << 4) * step;
 #pragma unroll
         for (int i = 0; i < 16; ++i, idx += step) v[i] = f.from_mem(data[idx]);
-        static_for<0, 16>([&](auto I) { constexpr int i = decltype(I)::value; v[i] = f.twiddled(v[i], pass_twiddle(I)); });
-        dit_blocks_rt<F>(ql, v, f, rI);
+        static_for<0, 16>([&](auto I) { constexpr int i = decltype(I)::value; NTT_MATH64(v[i] = f.twiddled(v[i], pass_twiddle(I))); });
+        NTT_MATH64(dit_blocks_rt<F, true>(ql, v, f, rI));
 #pragma unroll
         for (int i = 0; i < 16; ++i) lds[(((grp << 4) + i) << logW) + x] = v[i];
         __syncthreads();
@@ -266,9 +283,10 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 const V r = lds[((row0 + m * sub) << logW) + x];
-                v[m] = m ? f.twiddled(r, f.tw_from_mem(T[m])) : r;
+                v[m] = r;
+                NTT_MATH64(v[m] = m ? f.twiddled(r, f.tw_from_mem(T[m])) : f.settle(r));
             }
-            dit_blocks<F, 4>(v, f, rI);
+            NTT_MATH64(dit_blocks<F, 4, true>(v, f, rI));
             if (b < q) {
 #pragma unroll
                 for (int m = 0; m < 16; ++m) lds[((row0 + m * sub) << logW) + x] = v[m];
@@ -348,17 +366,17 @@ __global__ void __launch_bounds__(LOCAL64_T) k64_local(uint64_t* data, const uin
 #pragma unroll
                     for (int k = 0; k < 16; ++k) v[k] = lds[local_slot(e0 + k * sub)];
                 }
-                dif_blocks<F, 4>(v, f, rF);
+                NTT_MATH64(dif_blocks<F, 4, true>(v, f, rF); v[0] = f.settle(v[0]));
                 const uint64_t* T = rt.f[b] + ((size_t)j << 4);
 #pragma unroll
-                for (int pos = 1; pos < 16; ++pos) v[pos] = f.twiddled(v[pos], f.tw_from_mem(T[pos]));
+                for (int pos = 1; pos < 16; ++pos) NTT_MATH64(v[pos] = f.twiddled(v[pos], f.tw_from_mem(T[pos])));
 #pragma unroll
                 for (int k = 0; k < 16; ++k) lds[local_slot(e0 + k * sub)] = v[k];
                 __syncthreads();
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = lds[local_slot((t << 4) + i)];
-            dif_blocks_rt<F>(ql, v, f, rF);
+            NTT_MATH64(dif_blocks_rt<F, true>(ql, v, f, rF));      // unreduced results: the store reduces
 #pragma unroll
             for (int i = 0; i < 16; ++i) lds[local_slot((t << 4) + i)] = v[i];
             __syncthreads();
@@ -367,7 +385,7 @@ __global__ void __launch_bounds__(LOCAL64_T) k64_local(uint64_t* data, const uin
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = lds[local_slot((t << 4) + i)];
-            dit_blocks_rt<F>(ql, v, f, rI);
+            NTT_MATH64(dit_blocks_rt<F, true>(ql, v, f, rI));
 #pragma unroll
             for (int i = 0; i < 16; ++i) lds[local_slot((t << 4) + i)] = v[i];
             bool stored = false;
@@ -380,9 +398,10 @@ __global__ void __launch_bounds__(LOCAL64_T) k64_local(uint64_t* data, const uin
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const V r = lds[local_slot(e0 + k * sub)];
-                    v[k] = k ? f.twiddled(r, f.tw_from_mem(T[k])) : r;
+                    v[k] = r;
+                    NTT_MATH64(v[k] = k ? f.twiddled(r, f.tw_from_mem(T[k])) : f.settle(r));
                 }
-                dit_blocks<F, 4>(v, f, rI);
+                NTT_MATH64(dit_blocks<F, 4, true>(v, f, rI));
                 if (direct && b == m) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k) emit(e0 + k * sub, v[k]);
@@ -396,6 +415,94 @@ __global__ void __launch_bounds__(LOCAL64_T) k64_local(uint64_t* data, const uin
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { const int e = t + LOCAL64_T * i; emit(e, lds[local_slot(e)]); }
+            }
+        }
+        __syncthreads();   // the next chunk overwrites the LDS
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k64_core_mul: the middle of a product whose transforms end in full chunks (12 levels on 4096 consecutive values):
+// forward levels of chunk c of `data`, the same for `other`, pointwise product and the inverse levels, result back
+// into `data` -- one read of each spectrum-to-be and one write instead of three round trips through memory.  The first
+// forward round reads memory and the last inverse round writes it in the order their threads need anyway; A's
+// transformed values wait in registers while B goes through the same LDS buffer, and the product enters the inverse
+// from the registers it was formed in.  The butterflies here keep their reductions (no LAZY levels): with A's values
+// parked the kernel sits at 125 registers = four waves per SIMD, the unreduced variants need 145-196 and measured
+// the same or slower (160 us against 160-175 us for 64 products of 2^18 points).
+// ---------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(LOCAL64_T) k64_core_mul(uint64_t* data, const uint64_t* other, uint64_t n_chunks,
+                                                          typename F::Consts fc, RoundTables64 rt) {
+    typedef typename F::V V;
+    typedef typename F::W W;
+    __shared__ V lds[LOCAL64_N];
+    const F f(fc);
+    W rF[8], rI[8];
+    load_roots<F>(rF, rI, fc);
+    const int t = threadIdx.x;
+    constexpr int m = LOCAL64_LOG;
+    V v[16], a[16];
+    for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        uint64_t* base = data + chunk * (uint64_t)LOCAL64_N;
+        const uint64_t* base_b = other + chunk * (uint64_t)LOCAL64_N;
+        auto forward = [&](const uint64_t* src) {
+            for (int b = m; b > 4; b -= 4) {
+                NTT_FENCE64();
+                const int sub = 1 << (b - 4);
+                const int blk = t >> (b - 4), j = t & (sub - 1);
+                const int e0 = (blk << b) + j;
+                if (b == m) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] = f.from_mem(src[e0 + k * sub]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] = lds[local_slot(e0 + k * sub)];
+                }
+                NTT_MATH64(dif_blocks<F, 4>(v, f, rF));
+                const uint64_t* T = rt.f[b] + ((size_t)j << 4);
+#pragma unroll
+                for (int pos = 1; pos < 16; ++pos) NTT_MATH64(v[pos] = f.twiddled(v[pos], f.tw_from_mem(T[pos])));
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[local_slot(e0 + k * sub)] = v[k];
+                __syncthreads();
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = lds[local_slot((t << 4) + i)];
+            NTT_MATH64(dif_blocks<F, 4>(v, f, rF));
+        };
+        forward(base);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = v[i];
+        NTT_FENCE64();
+        __syncthreads();            // every thread has taken its sixteen values before the next first round overwrites them
+        forward(base_b);
+        NTT_FENCE64();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = f.mulpw(a[i], v[i]);
+        NTT_MATH64(dit_blocks<F, 4>(v, f, rI));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lds[local_slot((t << 4) + i)] = v[i];   // the thread's own slots: no barrier needed before
+        for (int b = 8; b <= m; b += 4) {
+            __syncthreads();
+            NTT_FENCE64();
+            const int sub = 1 << (b - 4);
+            const int blk = t >> (b - 4), j = t & (sub - 1);
+            const int e0 = (blk << b) + j;
+            const uint64_t* T = rt.i[b] + ((size_t)j << 4);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const V r = lds[local_slot(e0 + k * sub)];
+                v[k] = r;
+                NTT_MATH64(if (k) v[k] = f.twiddled(r, f.tw_from_mem(T[k])));
+            }
+            NTT_MATH64(dit_blocks<F, 4>(v, f, rI));
+            if (b == m) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) base[e0 + k * sub] = f.to_mem(v[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[local_slot(e0 + k * sub)] = v[k];
             }
         }
         __syncthreads();   // the next chunk overwrites the LDS

@@ -2,6 +2,7 @@
 # builds diagnostic variants of the library (wrong results by construction, timing only) into tools/ablate/
 #   core:    the fused core without barriers, global loads and LDS traffic
 #   strided: the column passes without their butterflies and twiddle multiplies (their memory floor)
+#   math64:  the 64-bit tile and chunk passes without their arithmetic (their memory floor)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/ablate
@@ -12,4 +13,5 @@ build() {  # name, defines...
 build core -DNTT_ABLATE_BARRIER -DNTT_ABLATE_GLOAD -DNTT_ABLATE_LDS
 build gload -DNTT_ABLATE_GLOAD
 build strided -DNTT_ABLATE_STRIDED_MATH
+build math64 -DNTT_ABLATE64_MATH -ffp-contract=off
 ls -la tools/ablate

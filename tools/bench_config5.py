@@ -37,9 +37,15 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--direct-only", action="store_true")
     ap.add_argument("--warm", type=int, default=4, help="untimed products before the timed ones")
+    ap.add_argument("--lib", default=None, help="a diagnostic build of the library (tools/ablate.sh) instead of the shipped one")
     args = ap.parse_args()
     n = 1 << args.log_n
-    lib = load_product_library(); lib.init(0)
+    if args.lib:
+        from ntt_amd._binding import NttLibrary
+        lib = NttLibrary(os.path.abspath(args.lib))
+    else:
+        lib = load_product_library()
+    lib.init(0)
     torch.cuda.set_device(0)
     st = torch.cuda.current_stream().cuda_stream
     gen = torch.Generator(device="cuda"); gen.manual_seed(5)

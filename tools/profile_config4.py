@@ -1,10 +1,14 @@
 """Per-kernel times of the four-prime CRT product (n = 2^17, p = 1337006139375617) in steady state.
-usage: python tools/profile_config4.py [batch] [auto|reference]   (route policy: direct 64-bit field / four-prime CRT)"""
+usage: python tools/profile_config4.py [--lib path.so] [batch] [auto|reference]   (route policy: direct 64-bit field / four-prime CRT)"""
 import ctypes, sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, torch
-from ntt_amd._binding import load_product_library
-lib = load_product_library(); lib.init(0)
+from ntt_amd._binding import load_product_library, NttLibrary
+if len(sys.argv) > 2 and sys.argv[1] == "--lib":      # a diagnostic build (tools/ablate.sh)
+    lib = NttLibrary(os.path.abspath(sys.argv[2])); del sys.argv[1:3]
+else:
+    lib = load_product_library()
+lib.init(0)
 lib.set_route_policy(sys.argv[2] if len(sys.argv) > 2 else "auto")
 L = lib.lib
 B, n, p = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), 131072, 1337006139375617
