@@ -110,6 +110,69 @@ def valu_roofline(kernel, batch, avg_ms):
         return None
 
 
+def other_configurations(torch, lib, stream):
+    """The remaining single-GPU configurations of the baseline, timed on the idle GPU after the headline (same entry
+    points, operands resident in HBM, steady state after an untimed ramp).  Reported beside the headline, never as
+    `value`; their bit-exactness is the business of the GPU test suite, here each result is only spot-checked by the
+    evaluation identity c(1) = a(1) b(1) mod p on one product."""
+    L = lib.lib
+    big = 1337006139375617
+    out = []
+
+    def timed(fn, reps, ramp_s=0.15):
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < ramp_s:
+            fn()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def at_one(t, p):        # sum of a non-negative int64 vector modulo p without overflow
+        t = t.reshape(-1)
+        while t.numel() > 1:
+            pad = (-t.numel()) % 1024
+            if pad:
+                t = torch.cat([t, torch.zeros(pad, dtype=t.dtype, device=t.device)])
+            t = t.view(-1, 1024).sum(dim=1) % p
+        return int(t.item())
+
+    def run(name, n, p, batch, wide, reps, policy="auto"):
+        gen = torch.Generator(device="cuda"); gen.manual_seed(n + batch)
+        a = torch.randint(0, p, (batch, n), generator=gen, device="cuda", dtype=torch.int64)
+        b = torch.randint(0, p, (batch, n), generator=gen, device="cuda", dtype=torch.int64)
+        if not wide:
+            a, b = a.to(torch.int32), b.to(torch.int32)
+        c = torch.zeros((batch, 2 * n - 1), dtype=a.dtype, device="cuda")
+        lib.set_route_policy(policy)
+        try:
+            fn_c = L.ntt_poly_multiply_batched_device_u64 if wide else L.ntt_poly_multiply_batched_device
+            def fn():
+                lib.check(fn_c(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, p, batch, n, n, 2 * n - 1, None, 0, stream))
+            dt = timed(fn, reps)
+            kernels = lib.describe_plan(n, p)
+        finally:
+            lib.set_route_policy("auto")
+        r = batch - 1
+        ok = at_one(a[r].to(torch.int64), p) * at_one(b[r].to(torch.int64), p) % p == at_one(c[r].to(torch.int64), p)
+        out.append({"config": name, "n": n, "p": p, "batch": batch, "ms_per_call": dt * 1e3, "poly_mults_per_s": batch / dt,
+                    "kernels": kernels, "spot_check": bool(ok)})
+
+    jobs = [("65536 x n=4096 (batched small products)", 4096, 998244353, 65536, False, 10, "auto"),
+            ("large modulus n=2^17, 64 products (direct 64-bit field, default route)", 131072, big, 64, True, 20, "auto"),
+            ("large modulus n=2^17, 64 products (four-prime CRT, the reference's route)", 131072, big, 64, True, 20, "reference"),
+            ("one product of n=2^28 coefficients, large modulus", 1 << 28, big, 1, True, 3, "auto")]
+    for job in jobs:
+        try:
+            run(*job)
+        except Exception as e:   # a failure here must not take the headline line with it
+            out.append({"config": job[0], "error": f"{type(e).__name__}: {e}"})
+        torch.cuda.empty_cache()
+    return out
+
+
 def free_port():
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -193,6 +256,8 @@ def main():
                          "Infinity Cache from the step before")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the timing of the other single-GPU configurations after the headline (N = 1 only)")
     ap.add_argument("--lib", default=None, help="diagnostic: load this build of the library instead of the shipped one")
     ap.add_argument("--no-verify", action="store_true", help="diagnostic: skip the result checks (ablated builds)")
     ap.add_argument("--rehearse-cpu", action="store_true",
@@ -408,6 +473,10 @@ def main():
                 "roofline": roofline}
         if cpu:
             line["rehearsal"] = "CPU twin over gloo: control-flow rehearsal, not a measurement"
+        if world == 1 and not cpu and not args.no_other_configs and not args.lib:
+            del a_sets, b_sets, out, ws
+            torch.cuda.empty_cache()
+            line["other_configs"] = other_configurations(torch, lib, stream)
         if world == 1 and not args.no_cpu_baseline and not cpu:
             line["cpu_baseline"] = cpu_baseline(n, p)
         print(json.dumps(line), flush=True)

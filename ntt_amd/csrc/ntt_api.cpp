@@ -22,6 +22,7 @@
 
 #include <condition_variable>
 #include <functional>
+#include <algorithm>
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -1909,8 +1910,21 @@ int ntt_describe_plan(int n, uint64_t p, char* buf, size_t buf_len) {
     const char* pipe = logL <= 12 ? ((logL >= 5 && p < (1ull << 31) && (p - 1) % 64 == 0) ? "k_small16" : "k_small") : logL == 13 ? "k_fused8192" : "k_fwd_strided,k_core_mul,k_inv_strided";
     if (route == ROUTE_DIRECT32) s = pipe;
     else if (route == ROUTE_CRT) s = std::string("4x(") + pipe + "),k_crt_merge";
-    else if (route == ROUTE_FIELD64) s = "k64_tile,k64_local,k64_strided,k64_load,k64_pointwise,k64_finalize";
-    else if (route == ROUTE_WIDECRT) s = "k64_tile,k64_local,k64_strided,k64_load,k64_pointwise,k64_finalize,k64_garner";
+    else if (route == ROUTE_FIELD64 || route == ROUTE_WIDECRT) {
+        // the launches of one product in the 64-bit field, in order of first use
+        const std::vector<Step64> steps = plan_steps(logL, 1, 1);
+        const bool fused = steps.size() >= 2 && steps.front().kind == Step64::TILE && steps.back().kind == Step64::LOCAL;
+        const bool core = fused && steps.back().q == LOCAL64_LOG && fused_core_allowed();
+        std::vector<std::string> names;
+        auto add = [&](const char* k) { if (std::find(names.begin(), names.end(), k) == names.end()) names.push_back(k); };
+        if (!fused) add("k64_load");
+        for (const Step64& st : steps)
+            add(st.kind == Step64::TILE ? "k64_tile" : st.kind == Step64::REG ? "k64_strided" : st.kind == Step64::SMALL ? "k64_small"
+                : core ? "k64_core_mul" : "k64_local");
+        if (!fused) { add("k64_pointwise"); add("k64_finalize"); }
+        if (route == ROUTE_WIDECRT) add("k64_garner");
+        for (size_t i = 0; i < names.size(); ++i) s += (i ? "," : "") + names[i];
+    }
     else return fail(NTT_ERR_MODULUS, why);
     snprintf(buf, buf_len, "%s", s.c_str());
     return NTT_OK;

@@ -39,6 +39,11 @@ def test_bench_line_has_the_contract_keys():
     assert roof["valu"] is not None and 0 < roof["valu"]["frac"] < 1.5 and roof["valu"]["kernel"] == roof["dominant_kernel"]["kernel"]
     ver = d["verification"]
     assert ver["all_products_evaluation_identity"] is True and ver["rows_checked"] == 8 and ver["oracle_ok"] is True
+    # the other single-GPU configurations are timed beside the headline, each with a spot check of its result
+    others = d["other_configs"]
+    assert len(others) == 4 and all("error" not in o for o in others), others
+    assert all(o["spot_check"] is True and o["poly_mults_per_s"] > 0 for o in others)
+    assert others[1]["kernels"].startswith("k64_") and others[2]["kernels"].endswith("k_crt_merge")
 
 
 def test_more_gpus_than_the_node_has_is_an_error_not_a_smaller_run():
