@@ -65,3 +65,46 @@ def test_random_shapes_u32_device(gpu_lib, oracle):
             want = expected(oracle, a[r, :n].astype(np.uint64), b[r, :n].astype(np.uint64), p)
             assert np.array_equal(res[r, :2 * n - 1].astype(np.uint64), want), (case, n, p, batch, r)
             assert (res[r, 2 * n - 1:] == np.uint32(2**32 - 1)).all(), "wrote past 2n-1"
+
+
+def test_random_long_shapes_through_the_64bit_field(gpu_lib, oracle):
+    """Lengths where the 64-bit route runs its tile passes and fused core (transform lengths 2^17 .. 2^19), ragged n,
+    padded rows, a caller workspace of exactly the advertised size, values at the top of the range."""
+    import torch
+    big = 1337006139375617
+    rng = np.random.default_rng(646464)
+    L = gpu_lib.lib
+    st = torch.cuda.current_stream().cuda_stream
+    for case in range(8):
+        n = int(rng.integers(32769, 140000)) if case % 4 else [65536, 131072][case // 4]
+        p = big if case % 2 == 0 else int(rng.choice([998244353, 469762049]))
+        batch = int(rng.integers(1, 4))
+        sa, sb, so = n + int(rng.integers(0, 7)), n + int(rng.integers(0, 7)), 2 * n - 1 + int(rng.integers(0, 7))
+        a = rng.integers(0, p, (batch, sa), dtype=np.uint64); b = rng.integers(0, p, (batch, sb), dtype=np.uint64)
+        if case == 2:
+            a[:, :n] = p - 1; b[:, :n] = p - 1
+        da = torch.from_numpy(a.view(np.int64)).cuda(); db = torch.from_numpy(b.view(np.int64)).cuda()
+        out = torch.full((batch, so), -1, dtype=torch.int64, device="cuda")
+        ws_bytes = L.ntt64_workspace_bytes_batched(n, batch)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+        gpu_lib.check(L.ntt64_poly_multiply_batched_device(da.data_ptr(), db.data_ptr(), out.data_ptr(), n, p, batch, sa, sb, so,
+                                                           ws.data_ptr(), ws_bytes, st))
+        torch.cuda.synchronize()
+        res = out.cpu().numpy().view(np.uint64)
+        m = 1 << (n - 1).bit_length()
+        for r in range(batch):
+            if 2 * m <= (1 << 18):
+                az = np.zeros(m, dtype=np.uint64); bz = np.zeros(m, dtype=np.uint64); az[:n] = a[r, :n]; bz[:n] = b[r, :n]
+                want = oracle.poly_multiply_u64(az, bz, p)[:2 * n - 1]
+                assert np.array_equal(res[r, :2 * n - 1], want), (case, n, p, batch, r)
+            else:   # beyond the oracle's transform lengths: evaluation identities at x = 1 and x = -1
+                c = res[r, :2 * n - 1]
+                def ev(v, sign):
+                    return (int(v[0::2].astype(object).sum()) + sign * int(v[1::2].astype(object).sum())) % p
+                assert int(c.max()) < p
+                for sign in (1, -1):
+                    assert ev(a[r, :n], sign) * ev(b[r, :n], sign) % p == ev(c, sign), (case, n, p, sign)
+            assert (res[r, 2 * n - 1:] == np.uint64(2**64 - 1)).all(), "wrote past 2n-1"
+        too_small = max(ws_bytes - 8, 0)
+        assert L.ntt64_poly_multiply_batched_device(da.data_ptr(), db.data_ptr(), out.data_ptr(), n, p, batch, sa, sb, so,
+                                                    ws.data_ptr(), too_small, st) == -4
