@@ -154,6 +154,15 @@ uint32_t ntt_crt_prime(int prime_index);
  *   part_stride words apart, each holding `rows` rows of 2^(log_cols-log_parts) consecutive columns.  `rows` may be a
  *   sub-range of a part (pass d_rows + first_row * 2^(log_cols-log_parts)), so that arriving chunks can be transformed
  *   while later ones are still in flight.
+ * ntt64_fourstep_rows_load_device / ntt64_fourstep_rows_store_device: the same row-axis passes with the element-wise
+ *   ends of a product folded in.  load: forward, reading any 64-bit words from d_src (a slab of the same shape; rows
+ *   from rows_valid on count as zero and are never read -- the zero padding of the operands) and leaving the result in
+ *   d_slab.  store: inverse on d_slab, the last pass writing the scaled canonical coefficients (what
+ *   ntt64_finalize_device produces) to d_out, same shape.
+ * ntt64_fourstep_cols_product_device: the middle of a four-step product between the exchanges, on the layout of
+ *   ntt64_fourstep_cols_device: forward column-axis levels of d_a_rows and d_b_rows, pointwise product, inverse
+ *   column-axis levels, result in d_a_rows (d_b_rows is overwritten with its spectrum).  When a part's transforms end
+ *   in full 4096-word chunks the last forward passes, the product and the first inverse pass are one kernel.
  * ntt64_pointwise_device: a[i] = a[i]*b[i]*c mod p, c a constant of the arithmetic in use for p (2^-64 in Montgomery
  *   integers, 1 in double precision) that ntt64_finalize_device undoes.
  * ntt64_load_device: dst[row][i] = i < n ? src[row*src_stride + i] mod p : 0, i < len (may be in place).
@@ -169,6 +178,12 @@ int ntt64_fourstep_rows_device(uint64_t *d_slab, uint64_t p, int log_total, int 
                                int inverse, void *stream);
 int ntt64_fourstep_cols_device(uint64_t *d_rows, uint64_t p, int log_total, int log_cols, int log_parts, size_t part_stride,
                                size_t rows, int inverse, void *stream);
+int ntt64_fourstep_rows_load_device(const uint64_t *d_src, size_t rows_valid, uint64_t *d_slab, uint64_t p, int log_total,
+                                    int log_rows, size_t cols_local, uint64_t col0, void *stream);
+int ntt64_fourstep_rows_store_device(uint64_t *d_slab, uint64_t *d_out, uint64_t p, int log_total, int log_rows,
+                                     size_t cols_local, uint64_t col0, void *stream);
+int ntt64_fourstep_cols_product_device(uint64_t *d_a_rows, uint64_t *d_b_rows, uint64_t p, int log_total, int log_cols,
+                                       int log_parts, size_t part_stride, size_t rows, void *stream);
 int ntt64_twiddle_device(uint64_t *d_data, uint64_t p, int log_root, size_t rows, size_t cols, uint64_t row0,
                          uint64_t col0, int row_bits, int rows_bitrev, int inverse, void *stream);
 int ntt64_pointwise_device(uint64_t *d_a, const uint64_t *d_b, size_t count, uint64_t p, int log_root, void *stream);

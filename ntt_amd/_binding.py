@@ -25,7 +25,8 @@ EXPORTS = [
     "ntt_workspace_bytes", "ntt_poly_multiply_batched_device", "ntt_poly_multiply_batched_device_u64",
     "ntt_poly_multiply_batched_device_noalloc",
     "ntt_crt_merge_device", "ntt_crt_residue_product_device", "ntt_crt_prime", "ntt_describe_plan",
-    "ntt64_transform_device", "ntt64_fourstep_rows_device", "ntt64_fourstep_cols_device", "ntt64_twiddle_device", "ntt64_pointwise_device", "ntt64_load_device",
+    "ntt64_transform_device", "ntt64_fourstep_rows_device", "ntt64_fourstep_cols_device",
+    "ntt64_fourstep_rows_load_device", "ntt64_fourstep_rows_store_device", "ntt64_fourstep_cols_product_device", "ntt64_twiddle_device", "ntt64_pointwise_device", "ntt64_load_device",
     "ntt64_finalize_device", "ntt64_workspace_bytes", "ntt64_poly_multiply_device",
     "ntt64_workspace_bytes_batched", "ntt64_poly_multiply_batched_device",
     "ntt_transform_u64", "ntt_transform_device_u64",
@@ -81,6 +82,9 @@ class NttLibrary:
         L.ntt64_transform_device.argtypes = [vp, u64, ci, ci, sz, sz, ci, vp]; L.ntt64_transform_device.restype = ci
         L.ntt64_fourstep_rows_device.argtypes = [vp, u64, ci, ci, sz, u64, ci, vp]; L.ntt64_fourstep_rows_device.restype = ci
         L.ntt64_fourstep_cols_device.argtypes = [vp, u64, ci, ci, ci, sz, sz, ci, vp]; L.ntt64_fourstep_cols_device.restype = ci
+        L.ntt64_fourstep_rows_load_device.argtypes = [vp, sz, vp, u64, ci, ci, sz, u64, vp]; L.ntt64_fourstep_rows_load_device.restype = ci
+        L.ntt64_fourstep_rows_store_device.argtypes = [vp, vp, u64, ci, ci, sz, u64, vp]; L.ntt64_fourstep_rows_store_device.restype = ci
+        L.ntt64_fourstep_cols_product_device.argtypes = [vp, vp, u64, ci, ci, ci, sz, sz, vp]; L.ntt64_fourstep_cols_product_device.restype = ci
         L.ntt64_twiddle_device.argtypes = [vp, u64, ci, sz, sz, u64, u64, ci, ci, ci, vp]; L.ntt64_twiddle_device.restype = ci
         L.ntt64_pointwise_device.argtypes = [vp, vp, sz, u64, ci, vp]; L.ntt64_pointwise_device.restype = ci
         L.ntt64_load_device.argtypes = [vp, sz, sz, vp, sz, sz, u64, ci, vp]; L.ntt64_load_device.restype = ci

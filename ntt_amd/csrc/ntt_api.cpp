@@ -769,6 +769,25 @@ int transform64_f(const Plan64& pl, uint64_t* d, const Axis64& ax, bool inverse,
     return NTT_OK;
 }
 
+// The same with the outermost pass (first forward / last inverse) reading raw words from `src` or writing scaled
+// canonical results to `out` when that pass is a tile pass; returns false in *fused_io when it is not, and the caller
+// runs the separate load / finalize kernels instead.
+template <class F>
+int transform64_io(const Plan64& pl, uint64_t* d, const Axis64& ax, bool inverse, const TileExtra& io, bool* fused_io, hipStream_t st) {
+    const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer);
+    *fused_io = !steps.empty() && steps.front().kind == Step64::TILE;
+    const TileExtra none;
+    int rc;
+    if (!inverse) {
+        for (size_t i = 0; i < steps.size(); ++i)
+            if ((rc = run_step<F>(pl, d, steps[i], ax, false, (i == 0 && *fused_io) ? io : none, st)) != NTT_OK) return rc;
+    } else {
+        for (size_t i = steps.size(); i-- > 0;)
+            if ((rc = run_step<F>(pl, d, steps[i], ax, true, (i == 0 && *fused_io) ? io : none, st)) != NTT_OK) return rc;
+    }
+    return NTT_OK;
+}
+
 int transform64_axis(const Plan64& pl, uint64_t* d, const Axis64& ax, bool inverse, hipStream_t st) {
     if (ax.log_len + ax.col_bits > pl.log_root) return fail(NTT_ERR_ARG, "transform longer than the plan's root order");
     if (ax.log_len == 0 || ax.outer == 0 || ax.inner == 0) return NTT_OK;
@@ -823,6 +842,65 @@ int transform64_split(const Plan64& pl, uint64_t* d, int log_cols, int log_parts
     return parts_pass();
 }
 
+// NTT_CORE64=off keeps the last forward passes, the pointwise product and the first inverse pass as separate kernels
+// (A/B measurements)
+bool fused_core_allowed() {
+    static const bool v = [] { const char* e = getenv("NTT_CORE64"); return !(e && strcmp(e, "off") == 0); }();
+    return v;
+}
+
+void pointwise64(const Plan64& pl, uint64_t* a, const uint64_t* b, uint64_t count, hipStream_t st);
+
+// Forward column-axis transforms of two arrays in the split layout, their pointwise product and the inverse column-axis
+// transform of it, result in `a`: the middle of a four-step product, between the exchanges.  When the transforms inside
+// a part end in full chunks the last forward passes, the product and the first inverse pass are one kernel.
+template <class F>
+int product64_split_f(const Plan64& pl, uint64_t* a, uint64_t* b, int log_cols, int log_parts, uint64_t part_stride, uint64_t rows,
+                      hipStream_t st) {
+    const int log_cl = log_cols - log_parts;
+    const uint64_t cl = (uint64_t)1 << log_cl;
+    const TileExtra none;
+    int rc;
+    auto parts_pass = [&](uint64_t* d, bool inverse) -> int {
+        if (log_parts == 0) return NTT_OK;
+        Pass64 g{};
+        g.columns = rows * cl;
+        g.step = part_stride;
+        g.block_stride = 0;
+        g.n_blocks = 1;
+        g.q = log_parts;
+        g.hi_shift = 63;
+        g.lo_mask = cl - 1;
+        g.tw_stride = (uint64_t)1 << (pl.log_root - log_cols);
+        g.tw_mask = ((uint64_t)1 << pl.log_root) - 1;
+        return launch_pass<F>(pl, d, false, g, inverse, none, st);
+    };
+    if ((rc = parts_pass(a, false)) != NTT_OK || (rc = parts_pass(b, false)) != NTT_OK) return rc;
+    Axis64 ax;
+    ax.log_len = log_cl; ax.inner = 1; ax.outer = rows;
+    const std::vector<Step64> steps = log_cl > 0 ? plan_steps(log_cl, 1, rows) : std::vector<Step64>();
+    const bool core = !steps.empty() && steps.back().kind == Step64::LOCAL && steps.back().q == LOCAL64_LOG && fused_core_allowed();
+    const size_t n_outer = core ? steps.size() - 1 : steps.size();
+    for (uint64_t part = 0; part < ((uint64_t)1 << log_parts); ++part) {
+        uint64_t* pa = a + part * part_stride;
+        uint64_t* pb = b + part * part_stride;
+        for (size_t i = 0; i < n_outer; ++i)
+            if ((rc = run_step<F>(pl, pa, steps[i], ax, false, none, st)) != NTT_OK || (rc = run_step<F>(pl, pb, steps[i], ax, false, none, st)) != NTT_OK) return rc;
+        if (core) {
+            const uint64_t n_chunks = (rows << log_cl) >> LOCAL64_LOG;
+            const unsigned grid = (unsigned)(n_chunks < (1u << 20) ? n_chunks : (1u << 20));
+            NTT_LAUNCH_P("k64_core_mul", (k64_core_mul<F>), dim3(grid), dim3(LOCAL64_T), st, pa, (const uint64_t*)pb, n_chunks, consts_of<F>(pl), pl.rt);
+            HIP_TRY(hipGetLastError());
+        } else {
+            pointwise64(pl, pa, pb, rows * cl, st);
+            HIP_TRY(hipGetLastError());
+        }
+        for (size_t i = n_outer; i-- > 0;)
+            if ((rc = run_step<F>(pl, pa, steps[i], ax, true, none, st)) != NTT_OK) return rc;
+    }
+    return parts_pass(a, true);
+}
+
 // element-wise kernels, by field
 template <class F>
 void launch_load64(const Plan64& pl, const uint64_t* src, size_t src_stride, uint64_t n, uint64_t* dst, uint64_t len, uint64_t rows, hipStream_t st) {
@@ -847,13 +925,6 @@ void twiddle64(const Plan64& pl, uint64_t* d, uint64_t rows, uint64_t cols, uint
     const uint64_t mask = ((uint64_t)1 << pl.log_root) - 1;
     if (pl.fp) NTT_LAUNCH_P("k64_twiddle", (k64_twiddle<FieldD>), dim3(grid_for(rows * cols)), dim3(256), st, d, rows, cols, row0, col0, row_bits, rows_bitrev, inverse, (uint64_t)1, mask, pl.fd, pl.tw);
     else NTT_LAUNCH_P("k64_twiddle", (k64_twiddle<Field64>), dim3(grid_for(rows * cols)), dim3(256), st, d, rows, cols, row0, col0, row_bits, rows_bitrev, inverse, (uint64_t)1, mask, pl.fc, pl.tw);
-}
-
-// NTT_CORE64=off keeps the last forward passes, the pointwise product and the first inverse pass as separate kernels
-// (A/B measurements)
-bool fused_core_allowed() {
-    static const bool v = [] { const char* e = getenv("NTT_CORE64"); return !(e && strcmp(e, "off") == 0); }();
-    return v;
 }
 
 // `rows` products in the field at once, operands and results in caller memory, two work arrays of rows * L words.  When
@@ -1698,6 +1769,100 @@ int ntt64_fourstep_cols_device(uint64_t* d_rows, uint64_t p, int log_total, int 
     Plan64* pl = nullptr;
     if ((rc = get_plan64(dev, p, log_total, &pl)) != NTT_OK) return rc;
     return transform64_split(*pl, d_rows, log_cols, log_parts, (uint64_t)part_stride, (uint64_t)rows, inverse != 0, (hipStream_t)stream);
+}
+
+namespace {
+// shared argument checks and plan lookup of the four-step row-axis entry points
+int fourstep_rows_setup(const void* d_slab, uint64_t p, int log_total, int log_rows, size_t cols_local, uint64_t col0, Plan64** pl,
+                        Axis64* ax) {
+    if (!d_slab) return fail(NTT_ERR_ARG, "null pointer");
+    if (log_rows < 0 || log_rows > log_total || cols_local == 0 || !is_pow2(cols_local)) return fail(NTT_ERR_ARG, "slab shape: 0 <= log_rows <= log_total, cols_local a power of two");
+    const int log_cols = log_total - log_rows;
+    if (col0 + cols_local > ((uint64_t)1 << log_cols)) return fail(NTT_ERR_ARG, "slab columns exceed the matrix");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    if ((rc = get_plan64(dev, p, log_total, pl)) != NTT_OK) return rc;
+    ax->log_len = log_rows; ax->inner = cols_local; ax->outer = 1; ax->col_bits = log_cols; ax->col0 = col0;
+    if (log_cols == 0) { ax->col_bits = 0; ax->col0 = 0; }   // a matrix of one column is a plain transform
+    return NTT_OK;
+}
+}  // namespace
+
+int ntt64_fourstep_rows_load_device(const uint64_t* d_src, size_t rows_valid, uint64_t* d_slab, uint64_t p, int log_total, int log_rows,
+                                    size_t cols_local, uint64_t col0, void* stream) {
+    NTT_API_LOCK;
+    if (!d_src) return fail(NTT_ERR_ARG, "null pointer");
+    Plan64* pl = nullptr;
+    Axis64 ax;
+    int rc = fourstep_rows_setup(d_slab, p, log_total, log_rows, cols_local, col0, &pl, &ax);
+    if (rc != NTT_OK) return rc;
+    const uint64_t rows = (uint64_t)1 << log_rows;
+    if (rows_valid > rows) return fail(NTT_ERR_ARG, "more valid rows than the slab has");
+    hipStream_t st = (hipStream_t)stream;
+    TileExtra io;
+    io.src = d_src;
+    io.src_valid = (uint64_t)rows_valid * cols_local;   // row-major slab: the rows below rows_valid are its first elements
+    bool fused = false;
+    if (log_rows > 0) {
+        const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer);
+        fused = !steps.empty() && steps.front().kind == Step64::TILE;
+    }
+    if (!fused) {
+        load64(*pl, d_src, 0, io.src_valid, d_slab, rows * cols_local, 1, st);
+        HIP_TRY(hipGetLastError());
+        if (log_rows == 0) return NTT_OK;
+        return transform64_axis(*pl, d_slab, ax, false, st);
+    }
+    return pl->fp ? transform64_io<FieldD>(*pl, d_slab, ax, false, io, &fused, st) : transform64_io<Field64>(*pl, d_slab, ax, false, io, &fused, st);
+}
+
+int ntt64_fourstep_rows_store_device(uint64_t* d_slab, uint64_t* d_out, uint64_t p, int log_total, int log_rows, size_t cols_local,
+                                     uint64_t col0, void* stream) {
+    NTT_API_LOCK;
+    if (!d_out) return fail(NTT_ERR_ARG, "null pointer");
+    Plan64* pl = nullptr;
+    Axis64 ax;
+    int rc = fourstep_rows_setup(d_slab, p, log_total, log_rows, cols_local, col0, &pl, &ax);
+    if (rc != NTT_OK) return rc;
+    const uint64_t count = ((uint64_t)1 << log_rows) * cols_local;
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t Linv = h_powmod((1ull << log_total) % p, p - 2, p);
+    const uint64_t scale = h_mulmod(Linv, pointwise_compensation(*pl), p);
+    bool fused = false;
+    if (log_rows > 0) {
+        const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer);
+        fused = !steps.empty() && steps.front().kind == Step64::TILE;
+    }
+    if (!fused) {
+        if (log_rows > 0 && (rc = transform64_axis(*pl, d_slab, ax, true, st)) != NTT_OK) return rc;
+        finalize64(*pl, d_slab, count, d_out, 0, count, 1, scale, st);
+        HIP_TRY(hipGetLastError());
+        return NTT_OK;
+    }
+    TileExtra io;
+    io.out = d_out;
+    io.n_out = count;
+    io.scale_word = tw_word(*pl, scale);
+    return pl->fp ? transform64_io<FieldD>(*pl, d_slab, ax, true, io, &fused, st) : transform64_io<Field64>(*pl, d_slab, ax, true, io, &fused, st);
+}
+
+int ntt64_fourstep_cols_product_device(uint64_t* d_a_rows, uint64_t* d_b_rows, uint64_t p, int log_total, int log_cols, int log_parts,
+                                       size_t part_stride, size_t rows, void* stream) {
+    NTT_API_LOCK;
+    if (!d_a_rows || !d_b_rows) return fail(NTT_ERR_ARG, "null pointer");
+    if (log_cols < 0 || log_cols > log_total || log_parts < 0 || log_parts > log_cols || log_parts > 4) return fail(NTT_ERR_ARG, "bad shape");
+    if (log_parts > 0 && part_stride < (rows << (log_cols - log_parts))) return fail(NTT_ERR_ARG, "part stride smaller than a part");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    Plan64* pl = nullptr;
+    if ((rc = get_plan64(dev, p, log_total, &pl)) != NTT_OK) return rc;
+    if (rows == 0) return NTT_OK;
+    return pl->fp ? product64_split_f<FieldD>(*pl, d_a_rows, d_b_rows, log_cols, log_parts, (uint64_t)part_stride, (uint64_t)rows, (hipStream_t)stream)
+                  : product64_split_f<Field64>(*pl, d_a_rows, d_b_rows, log_cols, log_parts, (uint64_t)part_stride, (uint64_t)rows, (hipStream_t)stream);
 }
 
 int ntt64_twiddle_device(uint64_t* d_data, uint64_t p, int log_root, size_t rows, size_t cols, uint64_t row0, uint64_t col0,

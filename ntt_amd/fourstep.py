@@ -12,6 +12,12 @@ The length-L transform (L = 2^l >= 2n-1) is viewed as an R x C matrix, element i
 The spectra of both operands end up in the same (scrambled) order, the pointwise product is local, and the
 inverse runs the mirror sequence: three all-to-alls per product in total, each moving (G-1)/G of the rank's
 slab.  Everything is ordered on the device stream; the host never waits between the steps.
+A product (`multiply_slabs`) folds the element-wise ends into the passes next to them: the operands are reduced and
+zero-padded by the first row pass (`ntt64_fourstep_rows_load_device`, the padding rows are never read), the column
+passes of both operands, the pointwise product and the inverse column passes of a piece are one call
+(`ntt64_fourstep_cols_product_device`: their last forward levels, the product and the first inverse levels one
+kernel), and the last row pass writes the scaled canonical coefficients (`ntt64_fourstep_rows_store_device`).
+The matrix shape is chosen for the fewest passes over memory (`plan_shape`).
 This replaces the reference's distributed transform, which keeps the whole array on every rank and all-reduces
 it after every butterfly stage (main_mpi_t.cc:164-222).
 
@@ -25,14 +31,28 @@ def _log2(x):
     return x.bit_length() - 1
 
 
+def _passes(log_rows, log_cols_local, log_parts):
+    """Passes over memory of one transform for a matrix shape: the row axis goes through LDS tiles of up to 2^9 rows
+    (a register pass when it has fewer than 2^5), the column axis ends in one pass over 4096-word chunks with tiled
+    passes of up to 9 levels in front, plus a register pass over the parts an exchange leaves."""
+    rows = 1 if log_rows <= 4 else -(-log_rows // 9)
+    cols = 1 if log_cols_local <= 12 else 1 + -(-(log_cols_local - 12) // 9)
+    return rows + cols + (1 if log_parts else 0)
+
+
 def plan_shape(n, world):
-    """(log_total, log_rows, log_cols) for operands of n coefficients on `world` ranks."""
+    """(log_total, log_rows, log_cols) for operands of n coefficients on `world` ranks: of the shapes with the fewest
+    passes over memory per transform the one closest to square (the exchange then moves the squarest pieces)."""
     log_total = max(1, (2 * n - 2).bit_length()) if n > 1 else 1
-    log_rows = log_total // 2
     g = _log2(world)
-    log_rows = max(log_rows, g)
-    if log_total - log_rows < g:
+    if log_total < 2 * g:
         raise ValueError("transform too short for this many ranks")
+    best = None
+    for log_rows in range(g, log_total - g + 1):
+        cost = (_passes(log_rows, log_total - log_rows - g, g), abs(2 * log_rows - log_total), log_rows)
+        if best is None or cost < best[0]:
+            best = (cost, log_rows)
+    log_rows = best[1]
     return log_total, log_rows, log_total - log_rows
 
 
@@ -127,8 +147,51 @@ class FourStep:
         lib.check(L.ntt64_finalize_device(x.data_ptr(), x.numel(), out.data_ptr(), 0, x.numel(), 1, p, lt, self.log_total, self.stream))
         return out
 
-    def multiply_slabs(self, a_slab, b_slab):
-        """Column slabs of a and b -> column slab of the product."""
+    def multiply_slabs(self, a_slab, b_slab, rows_valid=None):
+        """Column slabs of a and b (any 64-bit words; rows from rows_valid on are taken as zero) -> column slab of the
+        product, canonical.  The slabs are overwritten."""
+        L, lib, p, lt, t = self.lib.lib, self.lib, self.p, self.log_total, self.torch
+        if rows_valid is None:
+            rows_valid = min(self.R, -(-self.n // self.C))       # rows of the matrix that hold coefficients
+        spectra = []
+        pending = []
+        pieces = self._row_pieces()
+        for slab in (a_slab, b_slab):
+            lib.check(L.ntt64_fourstep_rows_load_device(slab.data_ptr(), rows_valid, slab.data_ptr(), p, lt, self.log_rows, self.Cl,
+                                                        self.rank * self.Cl, self.stream))
+            if self.world == 1:
+                spectra.append(slab)
+                continue
+            send = slab.view(self.world, self.Rl, self.Cl)
+            recv = t.empty_like(send)
+            pending.append([self._exchange(send, recv, rows) for rows in pieces])
+            spectra.append(recv)
+        za, zb = spectra
+        if self.world == 1:
+            lib.check(L.ntt64_fourstep_cols_product_device(za.data_ptr(), zb.data_ptr(), p, lt, self.log_cols, 0, 0, self.R, self.stream))
+            x = za.view(self.R, self.Cl)
+        else:
+            back = t.empty_like(za)
+            returning = []
+            for k, (lo, hi) in enumerate(pieces):
+                for w in pending[0][k] + pending[1][k]:
+                    w.wait()                                        # orders the stream, not the host, on GPUs
+                off = 8 * lo * self.Cl
+                lib.check(L.ntt64_fourstep_cols_product_device(za.data_ptr() + off, zb.data_ptr() + off, p, lt, self.log_cols,
+                                                               self.log_parts, self.Rl * self.Cl, hi - lo, self.stream))
+                returning.append(self._exchange(za, back, (lo, hi)))   # travels while the next piece is worked on
+            for works in returning:
+                for w in works:
+                    w.wait()
+            x = back.view(self.R, self.Cl)
+        out = t.empty_like(x)
+        lib.check(L.ntt64_fourstep_rows_store_device(x.data_ptr(), out.data_ptr(), p, lt, self.log_rows, self.Cl, self.rank * self.Cl,
+                                                     self.stream))
+        return out
+
+    def multiply_slabs_stepwise(self, a_slab, b_slab):
+        """The same product from the separate transforms (forward, forward, pointwise, inverse): the form to use when the
+        spectra themselves are wanted."""
         za = self.forward(a_slab)
         zb = self.forward(b_slab)
         self.lib.check(self.lib.lib.ntt64_pointwise_device(za.data_ptr(), zb.data_ptr(), za.numel(), self.p, self.log_total, self.stream))

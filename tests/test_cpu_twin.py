@@ -181,6 +181,17 @@ def test_explicit_fourstep_matrix_form(twin, oracle):
         want = oracle.crt_ntt_multiply(az, bz, BIGP)[:2 * n - 1]
         assert np.array_equal(poly_multiply_fourstep(twin, a, b, BIGP, torch.device("cpu")), want), n
     assert plan_shape(1 << 28, 8) == (29, 14, 15)
+    assert plan_shape(1 << 28, 1) == (29, 17, 12)      # two tile passes over the rows, the column axis inside the fused core
+    # the fused product (operand load in the first row pass, column passes + pointwise in one call, canonical store in the
+    # last row pass) equals the product assembled from the separate transforms, on arbitrary 64-bit input words
+    from ntt_amd.fourstep import FourStep
+    for n in (3, 700, 9000, 40000):
+        a = rng.integers(0, 2**64, n, dtype=np.uint64); b = rng.integers(0, 2**64, n, dtype=np.uint64)
+        fs = FourStep(twin, BIGP, n, torch.device("cpu"))
+        fused = fs.gather(fs.multiply_slabs(fs.column_slab(a), fs.column_slab(b)))
+        stepwise = fs.gather(fs.multiply_slabs_stepwise(fs.column_slab(a), fs.column_slab(b)))
+        assert np.array_equal(fused, stepwise), n
+        assert np.array_equal(fused, oracle.schoolbook_u64(a % np.uint64(BIGP), b % np.uint64(BIGP), BIGP)) if n <= 9000 else True
 
 
 def test_route_selection_beyond_the_reference_range(twin):
