@@ -194,6 +194,22 @@ def test_explicit_fourstep_matrix_form(twin, oracle):
         assert np.array_equal(fused, oracle.schoolbook_u64(a % np.uint64(BIGP), b % np.uint64(BIGP), BIGP)) if n <= 9000 else True
 
 
+def test_fourstep_product_with_emulated_ranks(twin, oracle):
+    """All ranks of the sharded product in one process: the pass over the parts and the transforms on sub-ranges of a part."""
+    import torch
+    from fourstep_emulation import emulated_fourstep_product
+    to_dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64).copy())
+    from_dev = lambda t: t.numpy().view(np.uint64).copy()
+    rng = np.random.default_rng(44)
+    for world, n in ((2, 5), (2, 3000), (4, 20000), (8, 70000), (16, 9000), (1, 5000)):
+        a = rng.integers(0, 2**64, n, dtype=np.uint64); b = rng.integers(0, BIGP, n, dtype=np.uint64)
+        m = 1 << (n - 1).bit_length()
+        az = np.zeros(m, dtype=np.uint64); bz = np.zeros(m, dtype=np.uint64); az[:n] = a % np.uint64(BIGP); bz[:n] = b
+        want = oracle.crt_ntt_multiply(az, bz, BIGP)[:2 * n - 1]
+        got = emulated_fourstep_product(twin, a, b, BIGP, world, to_dev, from_dev, torch, None)
+        assert np.array_equal(got, want), (world, n)
+
+
 def test_route_selection_beyond_the_reference_range(twin):
     """Lengths above 2^18 and large moduli above the CRT bound go to the 64-bit field (shift property, exact)."""
     rng = np.random.default_rng(18)

@@ -83,6 +83,37 @@ def test_explicit_fourstep_single_gpu(gpu_lib, oracle, n):
     assert np.array_equal(poly_multiply_fourstep(gpu_lib, a, b, BIGP, torch.device("cuda", 0)), want)
 
 
+@pytest.mark.parametrize("world,n", [(2, 5), (2, 3000), (4, 20000), (8, 70000), (16, 9000), (8, 131072), (2, 100000)])
+def test_fourstep_product_with_emulated_ranks(gpu_lib, oracle, world, n):
+    """The multi-rank four-step product with every rank emulated on this one GPU (exchanges as tensor copies): the pass over
+    the parts and the transforms on sub-ranges of a part run as GPU kernels here, not only on real multi-GPU nodes."""
+    import torch
+    from fourstep_emulation import emulated_fourstep_product
+    to_dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64).copy()).cuda()
+    from_dev = lambda t: t.cpu().numpy().view(np.uint64).copy()
+    rng = np.random.default_rng(world * 1000 + n)
+    a = rng.integers(0, 2**64, n, dtype=np.uint64); b = rng.integers(0, BIGP, n, dtype=np.uint64)
+    m = 1 << (n - 1).bit_length()
+    az = np.zeros(m, dtype=np.uint64); bz = np.zeros(m, dtype=np.uint64); az[:n] = a % np.uint64(BIGP); bz[:n] = b
+    want = oracle.crt_ntt_multiply(az, bz, BIGP)[:2 * n - 1]
+    got = emulated_fourstep_product(gpu_lib, a, b, BIGP, world, to_dev, from_dev, torch, torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(got, want)
+
+
+def test_emulated_eight_rank_product_of_2_pow_24_equals_the_direct_one(gpu_lib):
+    """n = 2^24 over eight emulated ranks (matrix 2^12 x 2^13: tile passes over the rows, parts pass + fused core on the
+    columns) against the single-GPU direct product."""
+    import torch
+    from fourstep_emulation import emulated_fourstep_product
+    n = 1 << 24
+    rng = np.random.default_rng(24)
+    a = rng.integers(0, BIGP, n, dtype=np.uint64); b = rng.integers(0, BIGP, n, dtype=np.uint64)
+    to_dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64).copy()).cuda()
+    from_dev = lambda t: t.cpu().numpy().view(np.uint64).copy()
+    got = emulated_fourstep_product(gpu_lib, a, b, BIGP, 8, to_dev, from_dev, torch, torch.cuda.current_stream().cuda_stream, pieces=4)
+    assert np.array_equal(got, gpu_mul64(gpu_lib, a, b, BIGP))
+
+
 def test_long_product_beyond_the_crt_bound(gpu_lib):
     """n = 2^20 with the 51-bit modulus: past the four-prime CRT bound, so only the 64-bit field applies.
     Checked exactly on structured inputs (shift by a monomial, all-ones) and at x = 1 and x = -1 on random ones."""
