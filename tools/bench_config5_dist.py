@@ -54,15 +54,13 @@ def main():
     args = ap.parse_args()
     n = 1 << args.log_n
     world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    backend = os.environ.get("NTT_BENCH_BACKEND", "nccl")   # gloo: rehearsal of the rank logic with several ranks on one GPU
-    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        # RCCL only: its transfers are ordered on the device stream, which the product relies on.  (gloo moves device
+        # tensors from the host side without that ordering; the rank logic is rehearsed on CPU tensors in
+        # tests/test_distributed.py and with emulated ranks on one GPU in tests/fourstep_emulation.py.)
+        dist.init_process_group("nccl", device_id=dev)
     lib = load_product_library(); lib.init(0)
     fs = FourStep(lib, P, n, dev, dist if world > 1 else None)
 
