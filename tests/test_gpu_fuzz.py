@@ -108,3 +108,37 @@ def test_random_long_shapes_through_the_64bit_field(gpu_lib, oracle):
         too_small = max(ws_bytes - 8, 0)
         assert L.ntt64_poly_multiply_batched_device(da.data_ptr(), db.data_ptr(), out.data_ptr(), n, p, batch, sa, sb, so,
                                                     ws.data_ptr(), too_small, st) == -4
+
+
+def test_both_large_modulus_routes_agree_on_random_shapes(gpu_lib):
+    """The direct 64-bit field and the four-prime CRT are independent computations of the same residues (different
+    kernels, different arithmetic: exact doubles against 32-bit Montgomery + 128-bit merge): 150 random shapes up to
+    n = 2^17, ragged lengths, padded rows, values up to p - 1, compared with each other bit for bit."""
+    import torch
+    big = 1337006139375617
+    rng = np.random.default_rng(31337)
+    L = gpu_lib.lib
+    st = torch.cuda.current_stream().cuda_stream
+    try:
+        for case in range(150):
+            hi = [64, 5000, 131072][case % 3]
+            n = int(rng.integers(1, hi + 1)) if case % 7 else int(2 ** rng.integers(0, hi.bit_length()))
+            batch = int(rng.integers(1, 6)) if n > 20000 else int(rng.integers(1, 40))
+            sa, sb, so = n + int(rng.integers(0, 4)), n + int(rng.integers(0, 4)), 2 * n - 1 + int(rng.integers(0, 4))
+            a = torch.randint(0, big, (batch, sa), device="cuda", dtype=torch.int64)
+            b = torch.randint(0, big, (batch, sb), device="cuda", dtype=torch.int64)
+            if case % 10 == 0:
+                a.fill_(big - 1); b.fill_(big - 1)
+            outs = []
+            for policy in ("auto", "reference"):
+                gpu_lib.set_route_policy(policy)
+                out = torch.full((batch, so), -1, dtype=torch.int64, device="cuda")
+                gpu_lib.check(L.ntt_poly_multiply_batched_device_u64(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, big, batch, sa, sb, so,
+                                                                     None, 0, st))
+                outs.append(out)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0], outs[1]), (case, n, batch)
+            assert int(outs[0][:, :2 * n - 1].max()) < big and int(outs[0][:, :2 * n - 1].min()) >= 0
+            assert bool((outs[0][:, 2 * n - 1:] == -1).all())
+    finally:
+        gpu_lib.set_route_policy("auto")
