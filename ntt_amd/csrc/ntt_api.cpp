@@ -678,9 +678,14 @@ int launch_pass(const Plan64& pl, uint64_t* d, bool tile, const Pass64& g, bool 
         const uint64_t threads = g.n_blocks * g.columns;
         if (threads / 256 >= (1ull << 31)) return fail(NTT_ERR_ARG, "transform too large for one launch");
         const unsigned grid = (unsigned)((threads + 255) / 256);
-#define NTT_REG_CASE(Q)                                                                                              \
-    if (inverse) NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, true>), dim3(grid), dim3(256), st, d, g, fc, pl.tw);  \
-    else NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, false>), dim3(grid), dim3(256), st, d, g, fc, pl.tw)
+        const typename F::W scale = scale_arg<F>(ex.scale_word);
+        const uint64_t* no_src = nullptr;
+        uint64_t* no_out = nullptr;
+#define NTT_REG_CASE(Q)                                                                                                                  \
+    if (inverse && ex.out) NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, true, false, true>), dim3(grid), dim3(256), st, d, no_src, ex.out, ex.n_out, scale, g, fc, pl.tw); \
+    else if (inverse) NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, true>), dim3(grid), dim3(256), st, d, no_src, no_out, (uint64_t)0, scale, g, fc, pl.tw);               \
+    else if (ex.src) NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, false, true, false>), dim3(grid), dim3(256), st, d, ex.src, no_out, (uint64_t)0, scale, g, fc, pl.tw);   \
+    else NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, false>), dim3(grid), dim3(256), st, d, no_src, no_out, (uint64_t)0, scale, g, fc, pl.tw)
         switch (g.q) {
             case 1: NTT_REG_CASE(1); break;
             case 2: NTT_REG_CASE(2); break;
@@ -775,7 +780,7 @@ int transform64_f(const Plan64& pl, uint64_t* d, const Axis64& ax, bool inverse,
 template <class F>
 int transform64_io(const Plan64& pl, uint64_t* d, const Axis64& ax, bool inverse, const TileExtra& io, bool* fused_io, hipStream_t st) {
     const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer);
-    *fused_io = !steps.empty() && steps.front().kind == Step64::TILE;
+    *fused_io = !steps.empty() && (steps.front().kind == Step64::TILE || steps.front().kind == Step64::REG);
     const TileExtra none;
     int rc;
     if (!inverse) {
@@ -943,7 +948,9 @@ int product64_rows(const Plan64& pl, const uint64_t* a, size_t sa, const uint64_
     ax.log_len = logL;
     ax.outer = rows;
     int rc;
-    const bool fused = steps.size() >= 2 && steps.front().kind == Step64::TILE && steps.back().kind == Step64::LOCAL;
+    // the first pass (tiled or register-only) can take the operands as they are and the last one write the results
+    const bool outer_pass = steps.front().kind == Step64::TILE || steps.front().kind == Step64::REG;
+    const bool fused = steps.size() >= 2 && outer_pass && steps.back().kind == Step64::LOCAL;
     if (!fused) {
         load64(pl, a, sa, n, wa, L, rows, st);
         load64(pl, b, sb, n, wb, L, rows, st);
@@ -1807,7 +1814,7 @@ int ntt64_fourstep_rows_load_device(const uint64_t* d_src, size_t rows_valid, ui
     bool fused = false;
     if (log_rows > 0) {
         const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer);
-        fused = !steps.empty() && steps.front().kind == Step64::TILE;
+        fused = !steps.empty() && (steps.front().kind == Step64::TILE || steps.front().kind == Step64::REG);
     }
     if (!fused) {
         load64(*pl, d_src, 0, io.src_valid, d_slab, rows * cols_local, 1, st);
@@ -1833,7 +1840,7 @@ int ntt64_fourstep_rows_store_device(uint64_t* d_slab, uint64_t* d_out, uint64_t
     bool fused = false;
     if (log_rows > 0) {
         const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer);
-        fused = !steps.empty() && steps.front().kind == Step64::TILE;
+        fused = !steps.empty() && (steps.front().kind == Step64::TILE || steps.front().kind == Step64::REG);
     }
     if (!fused) {
         if (log_rows > 0 && (rc = transform64_axis(*pl, d_slab, ax, true, st)) != NTT_OK) return rc;
@@ -2078,7 +2085,7 @@ int ntt_describe_plan(int n, uint64_t p, char* buf, size_t buf_len) {
     else if (route == ROUTE_FIELD64 || route == ROUTE_WIDECRT) {
         // the launches of one product in the 64-bit field, in order of first use
         const std::vector<Step64> steps = plan_steps(logL, 1, 1);
-        const bool fused = steps.size() >= 2 && steps.front().kind == Step64::TILE && steps.back().kind == Step64::LOCAL;
+        const bool fused = steps.size() >= 2 && steps.front().kind != Step64::SMALL && steps.back().kind == Step64::LOCAL;
         const bool core = fused && steps.back().q == LOCAL64_LOG && fused_core_allowed();
         std::vector<std::string> names;
         auto add = [&](const char* k) { if (std::find(names.begin(), names.end(), k) == names.end()) names.push_back(k); };

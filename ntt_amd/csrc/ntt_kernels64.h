@@ -511,9 +511,12 @@ __global__ void __launch_bounds__(LOCAL64_T) k64_core_mul(uint64_t* data, const 
 
 // ---------------------------------------------------------------------------
 // k64_strided: register-only pass, radix 2^Q (Q <= 4), one thread per column; any inner extent.
+// SRC_RAW (forward) / FINAL (inverse): as in k64_tile -- caller words in, scaled canonical values out, rows of a batch
+// addressed through g.row_shift and the strides.
 // ---------------------------------------------------------------------------
-template <class F, int Q, bool INVERSE>
-__global__ void __launch_bounds__(256) k64_strided(uint64_t* data, Pass64 g, typename F::Consts fc, Twiddle64 tw) {
+template <class F, int Q, bool INVERSE, bool SRC_RAW = false, bool FINAL = false>
+__global__ void __launch_bounds__(256) k64_strided(uint64_t* data, const uint64_t* src, uint64_t* out, uint64_t n_out,
+                                                   typename F::W scale, Pass64 g, typename F::Consts fc, Twiddle64 tw) {
     typedef typename F::V V;
     typedef typename F::W W;
     constexpr int R = 1 << Q;
@@ -524,11 +527,20 @@ __global__ void __launch_bounds__(256) k64_strided(uint64_t* data, Pass64 g, typ
     if (tid >= g.n_blocks * g.columns) return;
     const uint64_t col = tid % g.columns, blk = tid / g.columns;
     const uint64_t jq = pass_jq(g, col);
-    uint64_t* base = data + (blk * g.block_stride + col);
+    const uint64_t origin = blk * g.block_stride + col;
+    uint64_t* base = data + origin;
     const uint64_t step = g.step;
+    const uint64_t row_mask = ((uint64_t)1 << g.row_shift) - 1;
     V x[16];
 #pragma unroll
-    for (int r = 0; r < R; ++r) x[r] = f.from_mem(base[(uint64_t)r * step]);
+    for (int r = 0; r < R; ++r) {
+        if (SRC_RAW) {
+            const uint64_t idx = origin + (uint64_t)r * step, pos = idx & row_mask;
+            x[r] = pos < g.src_valid ? f.from_raw(src[(idx >> g.row_shift) * g.src_stride + pos]) : V(0);
+        } else {
+            x[r] = f.from_mem(base[(uint64_t)r * step]);
+        }
+    }
     if (!INVERSE) {
         dif_sub<F, Q, 0>(x, f, rF);
         static_for<1, R>([&](auto P) {
@@ -547,7 +559,14 @@ __global__ void __launch_bounds__(256) k64_strided(uint64_t* data, Pass64 g, typ
         dit_sub<F, Q, 0>(x, f, rI);
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) base[(uint64_t)r * step] = f.to_mem(x[r]);
+    for (int r = 0; r < R; ++r) {
+        if (FINAL) {
+            const uint64_t o = origin + (uint64_t)r * step, pos = o & row_mask;
+            if (pos < n_out) out[(o >> g.row_shift) * g.out_stride + pos] = f.canon(f.twiddled(x[r], scale));
+        } else {
+            base[(uint64_t)r * step] = f.to_mem(x[r]);
+        }
+    }
 }
 
 // contiguous blocks of 2^m <= 4096 values, radix-2 stages in LDS with a barrier per stage: the fall-back for arrays
