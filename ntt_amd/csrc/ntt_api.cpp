@@ -943,6 +943,14 @@ int product64_rows(const Plan64& pl, const uint64_t* a, size_t sa, const uint64_
     const uint64_t p = pl.fc.p;
     const uint64_t Linv = h_powmod((uint64_t)L % p, p - 2, p);
     const uint64_t scale = h_mulmod(Linv, pointwise_compensation(pl), p);
+    if (logL <= LOCAL64_LOG && fused_core_allowed()) {      // short products: one kernel, several products per workgroup
+        const uint64_t n_chunks = ((uint64_t)rows + (LOCAL64_N >> logL) - 1) / (LOCAL64_N >> logL);
+        const unsigned grid = (unsigned)(n_chunks < (1u << 20) ? n_chunks : (1u << 20));
+        NTT_LAUNCH_P("k64_short_mul", (k64_short_mul<F>), dim3(grid), dim3(LOCAL64_T), st, a, (uint64_t)sa, b, (uint64_t)sb, out, (uint64_t)so,
+                     (uint64_t)n, (uint64_t)(2 * n - 1), (uint64_t)rows, logL, scale_arg<F>(tw_word(pl, scale)), consts_of<F>(pl), pl.rt);
+        HIP_TRY(hipGetLastError());
+        return NTT_OK;
+    }
     const std::vector<Step64> steps = plan_steps(logL, 1, rows);
     Axis64 ax;
     ax.log_len = logL;
@@ -2089,11 +2097,14 @@ int ntt_describe_plan(int n, uint64_t p, char* buf, size_t buf_len) {
         const bool core = fused && steps.back().q == LOCAL64_LOG && fused_core_allowed();
         std::vector<std::string> names;
         auto add = [&](const char* k) { if (std::find(names.begin(), names.end(), k) == names.end()) names.push_back(k); };
+        if (logL <= LOCAL64_LOG && fused_core_allowed()) add("k64_short_mul");
+        else {
         if (!fused) add("k64_load");
         for (const Step64& st : steps)
             add(st.kind == Step64::TILE ? "k64_tile" : st.kind == Step64::REG ? "k64_strided" : st.kind == Step64::SMALL ? "k64_small"
                 : core ? "k64_core_mul" : "k64_local");
         if (!fused) { add("k64_pointwise"); add("k64_finalize"); }
+        }
         if (route == ROUTE_WIDECRT) add("k64_garner");
         for (size_t i = 0; i < names.size(); ++i) s += (i ? "," : "") + names[i];
     }

@@ -74,6 +74,13 @@ struct Pass64 {
 // compiler-only barrier: keeps the loads of a later phase from being hoisted over the arithmetic of an earlier one (the
 // registers they would occupy cost more in occupancy than the early issue gains)
 #define NTT_FENCE64() asm volatile("" ::: "memory")
+// makes a per-thread value opaque to the optimiser, so that the indices, row numbers and masks derived from it are
+// recomputed where they are used instead of being kept in registers across the whole kernel
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NTT_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define NTT_OPAQUE(x) asm volatile("" : "+r"(x))
+#endif
 
 #ifdef NTT_ABLATE64_MATH
 #define NTT_MATH64(...)
@@ -504,6 +511,100 @@ __global__ void __launch_bounds__(LOCAL64_T) k64_core_mul(uint64_t* data, const 
 #pragma unroll
                 for (int k = 0; k < 16; ++k) lds[local_slot(e0 + k * sub)] = v[k];
             }
+        }
+        __syncthreads();   // the next chunk overwrites the LDS
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k64_short_mul: whole products of transform length 2^m <= 4096 in one kernel, 4096 >> m of them per workgroup: operands
+// from caller memory (any words, rows of n values, zero padded to the transform length), forward levels of A and of B
+// in the same LDS buffer (A's values wait in registers), pointwise product, inverse levels, scaled canonical results
+// (n_out per row) to caller memory.  Same rounds as k64_local for chunks of several blocks.
+// ---------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(LOCAL64_T, 4) k64_short_mul(const uint64_t* a, uint64_t a_stride, const uint64_t* b, uint64_t b_stride,
+                                                           uint64_t* out, uint64_t out_stride, uint64_t n, uint64_t n_out, uint64_t rows,
+                                                           int m, typename F::W scale, typename F::Consts fc, RoundTables64 rt) {
+    typedef typename F::V V;
+    typedef typename F::W W;
+    __shared__ V lds[LOCAL64_N];
+    const F f(fc);
+    W rF[8], rI[8];
+    load_roots<F>(rF, rI, fc);
+    const int t = threadIdx.x;
+    const int ql = ((m - 1) & 3) + 1;
+    const uint64_t pos_mask = ((uint64_t)1 << m) - 1;
+    const uint64_t per_chunk = (uint64_t)LOCAL64_N >> m;                 // products per workgroup
+    const uint64_t n_chunks = (rows + per_chunk - 1) / per_chunk;
+    V v[16], va[16];
+    for (uint64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint64_t row0 = chunk * per_chunk;
+        auto forward = [&](const uint64_t* src, uint64_t stride) {
+            NTT_FENCE64();
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {     // four loads in flight at a time: the conversions need registers of their own
+                int e = t + LOCAL64_T * i;
+                NTT_OPAQUE(e);
+                const uint64_t row = row0 + ((uint64_t)e >> m), pos = (uint64_t)e & pos_mask;
+                lds[local_slot(e)] = (row < rows && pos < n) ? f.from_raw(src[row * stride + pos]) : V(0);
+            }
+            __syncthreads();
+            for (int bb = m; bb > 4; bb -= 4) {
+                NTT_FENCE64();
+                const int sub = 1 << (bb - 4);
+                const int blk = t >> (bb - 4), j = t & (sub - 1);
+                const int e0 = (blk << bb) + j;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = lds[local_slot(e0 + k * sub)];
+                dif_blocks<F, 4>(v, f, rF);
+                const uint64_t* T = rt.f[bb] + ((size_t)j << 4);
+#pragma unroll
+                for (int pos = 1; pos < 16; ++pos) v[pos] = f.twiddled(v[pos], f.tw_from_mem(T[pos]));
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[local_slot(e0 + k * sub)] = v[k];
+                __syncthreads();
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = lds[local_slot((t << 4) + i)];
+            dif_blocks_rt<F>(ql, v, f, rF);
+        };
+        forward(a, a_stride);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) va[i] = v[i];
+        NTT_FENCE64();
+        __syncthreads();            // every thread has taken its sixteen values before the buffer is filled again
+        forward(b, b_stride);
+        NTT_FENCE64();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = f.mulpw(va[i], v[i]);
+        dit_blocks_rt<F>(ql, v, f, rI);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lds[local_slot((t << 4) + i)] = v[i];   // the thread's own slots
+        for (int bb = ql + 4; bb <= m; bb += 4) {
+            __syncthreads();
+            NTT_FENCE64();
+            const int sub = 1 << (bb - 4);
+            const int blk = t >> (bb - 4), j = t & (sub - 1);
+            const int e0 = (blk << bb) + j;
+            const uint64_t* T = rt.i[bb] + ((size_t)j << 4);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const V r = lds[local_slot(e0 + k * sub)];
+                v[k] = k ? f.twiddled(r, f.tw_from_mem(T[k])) : r;
+            }
+            dit_blocks<F, 4>(v, f, rI);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) lds[local_slot(e0 + k * sub)] = v[k];
+        }
+        __syncthreads();
+        NTT_FENCE64();
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            int e = t + LOCAL64_T * i;
+            NTT_OPAQUE(e);
+            const uint64_t row = row0 + ((uint64_t)e >> m), pos = (uint64_t)e & pos_mask;
+            if (row < rows && pos < n_out) out[row * out_stride + pos] = f.canon(f.twiddled(lds[local_slot(e)], scale));
         }
         __syncthreads();   // the next chunk overwrites the LDS
     }

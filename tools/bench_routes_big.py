@@ -1,10 +1,14 @@
 """Large-modulus products (n = 2^17, p = 1337006139375617) through the four-prime CRT route and through the
-64-bit field directly, same inputs, steady state.  usage: python tools/bench_routes_big.py [batch] [n]"""
+64-bit field directly, same inputs, steady state.  usage: python tools/bench_routes_big.py [--lib path.so] [batch] [n]"""
 import sys, os, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, torch
-from ntt_amd._binding import load_product_library
-lib = load_product_library(); lib.init(0)
+from ntt_amd._binding import load_product_library, NttLibrary
+if len(sys.argv) > 2 and sys.argv[1] == "--lib":      # a diagnostic build
+    lib = NttLibrary(os.path.abspath(sys.argv[2])); del sys.argv[1:3]
+else:
+    lib = load_product_library()
+lib.init(0)
 L = lib.lib
 B, n, p = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), (int(sys.argv[2]) if len(sys.argv) > 2 else 131072), 1337006139375617
 rng = np.random.default_rng(1)
