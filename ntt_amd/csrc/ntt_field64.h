@@ -38,6 +38,7 @@ struct Field64 {
     typedef uint64_t V;   // register value
     typedef uint64_t W;   // twiddle (Montgomery form, < 2p)
     typedef Field64Consts Consts;
+    static constexpr int SHORT_MUL_WAVES = 3;   // waves per SIMD k64_short_mul is compiled for (register budget 168)
     uint64_t p, np, B, r2;
     NTT_HD explicit Field64(const Field64Consts& c) : p(c.p), np(c.np), B(2 * c.p), r2(c.r2) {}
 
@@ -140,6 +141,7 @@ struct FieldD {
     typedef double V;
     typedef double W;
     typedef FieldDConsts Consts;
+    static constexpr int SHORT_MUL_WAVES = 4;   // waves per SIMD k64_short_mul is compiled for (130 registers without the cap)
     double p, u, c40;
     NTT_HD explicit FieldD(const FieldDConsts& c) : p(c.p), u(c.u), c40(c.c40) {}
 

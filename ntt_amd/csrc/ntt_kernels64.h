@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(LOCAL64_T) k64_core_mul(uint64_t* data, const 
 // (n_out per row) to caller memory.  Same rounds as k64_local for chunks of several blocks.
 // ---------------------------------------------------------------------------
 template <class F>
-__global__ void __launch_bounds__(LOCAL64_T, 4) k64_short_mul(const uint64_t* a, uint64_t a_stride, const uint64_t* b, uint64_t b_stride,
+__global__ void __launch_bounds__(LOCAL64_T, F::SHORT_MUL_WAVES) k64_short_mul(const uint64_t* a, uint64_t a_stride, const uint64_t* b, uint64_t b_stride,
                                                            uint64_t* out, uint64_t out_stride, uint64_t n, uint64_t n_out, uint64_t rows,
                                                            int m, typename F::W scale, typename F::Consts fc, RoundTables64 rt) {
     typedef typename F::V V;
