@@ -650,7 +650,6 @@ struct TileExtra {           // fusions of a product's first and last pass
     const uint64_t* src = nullptr; uint64_t src_valid = 0;               // forward: raw operands, rows zero beyond src_valid
     uint64_t* out = nullptr; uint64_t n_out = 0; uint64_t scale_word = 0; // inverse: scaled canonical output
     const uint64_t* other = nullptr;                                      // inverse local pass: pointwise product first
-    int row_shift = 63;                                                   // log2 of a product's work row (63: one product)
     uint64_t src_stride = 0, out_stride = 0;                              // rows of the operands / results in caller memory
 };
 
@@ -724,7 +723,6 @@ int run_step(const Plan64& pl, uint64_t* d, const Step64& s, const Axis64& ax, b
         g.tw_mask = ((uint64_t)1 << pl.log_root) - 1;
         g.q = s.q;
         g.src_valid = ex.src_valid;
-        g.row_shift = ex.row_shift;
         g.src_stride = ex.src_stride;
         g.out_stride = ex.out_stride;
         g.hi_shift = 63;
@@ -980,7 +978,6 @@ int product64_rows(const Plan64& pl, const uint64_t* a, size_t sa, const uint64_
         TileExtra first;
         first.src = side ? b : a;
         first.src_valid = n;
-        first.row_shift = logL;
         first.src_stride = side ? sb : sa;
         for (size_t i = 0; i < n_outer; ++i)
             if ((rc = run_step<F>(pl, w, steps[i], ax, false, i == 0 ? first : none, st)) != NTT_OK) return rc;
@@ -994,7 +991,7 @@ int product64_rows(const Plan64& pl, const uint64_t* a, size_t sa, const uint64_
     for (size_t i = n_outer; i-- > 0;) {
         TileExtra ex;
         if (i + 1 == steps.size()) ex.other = wb;
-        if (i == 0) { ex.out = out; ex.n_out = 2 * n - 1; ex.scale_word = tw_word(pl, scale); ex.row_shift = logL; ex.out_stride = so; }
+        if (i == 0) { ex.out = out; ex.n_out = 2 * n - 1; ex.scale_word = tw_word(pl, scale); ex.out_stride = so; }
         if ((rc = run_step<F>(pl, wa, steps[i], ax, true, ex, st)) != NTT_OK) return rc;
     }
     return NTT_OK;

@@ -63,9 +63,9 @@ struct Pass64 {
     int q;                  // log2 rows
     uint64_t tiles_per_block;   // k64_tile: columns / W
     uint64_t src_valid;     // first pass of a product reading caller data: elements of a source row beyond this index are zero
-    // first / last pass of a batch of products: element e of the work array belongs to product e >> row_shift, position
-    // e & (2^row_shift - 1); the operands' rows are src_stride and the results' rows out_stride elements apart
-    int row_shift;
+    // first / last pass of a batch of products (always the outermost pass: one block = one product's work row): block b
+    // reads its operand row at src + b * src_stride and writes its result row at out + b * out_stride; the position of an
+    // element in the row is its offset inside the block
     uint64_t src_stride, out_stride;
 };
 
@@ -204,7 +204,6 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
     const uint64_t origin = blk_g * g.block_stride + col;       // element offset of row 0 of this column
     const uint64_t jq = pass_jq(g, col);
     const int ql = ((q - 1) & 3) + 1;                           // levels of the last (smallest) round, 1..4
-    const uint64_t row_mask = ((uint64_t)1 << g.row_shift) - 1;
     V v[16];
 
     // Pass twiddles of the 16 rows 16*grp + i that a thread holds in the last forward / first inverse round: row r holds
@@ -240,14 +239,12 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
             if (first) {
                 uint64_t idx = origin + (uint64_t)row0 * step;
                 const uint64_t dstep = (uint64_t)sub * step;
+                const uint64_t* src_row = SRC_RAW ? src + blk_g * g.src_stride : nullptr;   // uniform over the workgroup
+                uint64_t pos = col + (uint64_t)row0 * step;                                   // offset inside the block
 #pragma unroll
-                for (int m = 0; m < 16; ++m, idx += dstep) {
-                    if (SRC_RAW) {
-                        const uint64_t pos = idx & row_mask;
-                        v[m] = pos < g.src_valid ? f.from_raw(src[(idx >> g.row_shift) * g.src_stride + pos]) : V(0);
-                    } else {
-                        v[m] = f.from_mem(data[idx]);
-                    }
+                for (int m = 0; m < 16; ++m, idx += dstep, pos += dstep) {
+                    if (SRC_RAW) v[m] = pos < g.src_valid ? f.from_raw(src_row[pos]) : V(0);
+                    else v[m] = f.from_mem(data[idx]);
                 }
             } else {
 #pragma unroll
@@ -301,11 +298,12 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
             } else {
                 uint64_t o = origin + (uint64_t)row0 * step;
                 const uint64_t dstep = (uint64_t)sub * step;
+                uint64_t* out_row = FINAL ? out + blk_g * g.out_stride : nullptr;              // uniform over the workgroup
+                uint64_t pos = col + (uint64_t)row0 * step;
 #pragma unroll
-                for (int m = 0; m < 16; ++m, o += dstep) {
+                for (int m = 0; m < 16; ++m, o += dstep, pos += dstep) {
                     if (FINAL) {
-                        const uint64_t pos = o & row_mask;
-                        if (pos < n_out) out[(o >> g.row_shift) * g.out_stride + pos] = f.canon(f.twiddled(v[m], scale));
+                        if (pos < n_out) out_row[pos] = f.canon(f.twiddled(v[m], scale));
                     } else {
                         data[o] = f.to_mem(v[m]);
                     }
@@ -613,7 +611,7 @@ __global__ void __launch_bounds__(LOCAL64_T, F::SHORT_MUL_WAVES) k64_short_mul(c
 // ---------------------------------------------------------------------------
 // k64_strided: register-only pass, radix 2^Q (Q <= 4), one thread per column; any inner extent.
 // SRC_RAW (forward) / FINAL (inverse): as in k64_tile -- caller words in, scaled canonical values out, rows of a batch
-// addressed through g.row_shift and the strides.
+// addressed through the block index and the strides.
 // ---------------------------------------------------------------------------
 template <class F, int Q, bool INVERSE, bool SRC_RAW = false, bool FINAL = false>
 __global__ void __launch_bounds__(256) k64_strided(uint64_t* data, const uint64_t* src, uint64_t* out, uint64_t n_out,
@@ -631,13 +629,12 @@ __global__ void __launch_bounds__(256) k64_strided(uint64_t* data, const uint64_
     const uint64_t origin = blk * g.block_stride + col;
     uint64_t* base = data + origin;
     const uint64_t step = g.step;
-    const uint64_t row_mask = ((uint64_t)1 << g.row_shift) - 1;
     V x[16];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (SRC_RAW) {
-            const uint64_t idx = origin + (uint64_t)r * step, pos = idx & row_mask;
-            x[r] = pos < g.src_valid ? f.from_raw(src[(idx >> g.row_shift) * g.src_stride + pos]) : V(0);
+            const uint64_t pos = col + (uint64_t)r * step;
+            x[r] = pos < g.src_valid ? f.from_raw(src[blk * g.src_stride + pos]) : V(0);
         } else {
             x[r] = f.from_mem(base[(uint64_t)r * step]);
         }
@@ -662,8 +659,8 @@ __global__ void __launch_bounds__(256) k64_strided(uint64_t* data, const uint64_
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (FINAL) {
-            const uint64_t o = origin + (uint64_t)r * step, pos = o & row_mask;
-            if (pos < n_out) out[(o >> g.row_shift) * g.out_stride + pos] = f.canon(f.twiddled(x[r], scale));
+            const uint64_t pos = col + (uint64_t)r * step;
+            if (pos < n_out) out[blk * g.out_stride + pos] = f.canon(f.twiddled(x[r], scale));
         } else {
             base[(uint64_t)r * step] = f.to_mem(x[r]);
         }
