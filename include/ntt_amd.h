@@ -92,7 +92,8 @@ int ntt_poly_multiply_batched_u64(const uint64_t *a, const uint64_t *b, uint64_t
  * a_stride / b_stride / ab_stride elements apart (>= n, n, 2n-1).  Work is enqueued on `stream`
  * (a hipStream_t passed as void*; NULL = default stream) and the call returns without
  * synchronising.  `workspace` is device memory of at least ntt_workspace_bytes(n, p, batch) bytes
- * (NULL: the library uses and grows its own).  This is the path the benchmark times. */
+ * (NULL: the library uses and grows its own, one per stream); the size depends on the route that serves (n, p), so
+ * ask again after ntt_set_route_policy.  This is the path the benchmark times. */
 size_t ntt_workspace_bytes(int n, uint64_t p, size_t batch);
 int ntt_poly_multiply_batched_device(const uint32_t *d_a, const uint32_t *d_b, uint32_t *d_ab, int n, uint32_t p,
                                      size_t batch, size_t a_stride, size_t b_stride, size_t ab_stride,
