@@ -15,6 +15,14 @@
 //   k64_strided  register-only radix 2..16 pass for shapes the tiles do not fit (odd inner extents, tiny axes).
 //   k64_small    radix-2 stages in LDS for short contiguous axes in arrays smaller than one k64_local chunk.
 //
+// A product never runs its element-wise steps as passes of their own.  The outermost pass of a transform (k64_tile or
+// k64_strided) reads the caller's operands -- any 64-bit words, reduced on the fly, the zero padding never read -- and,
+// on the way back, writes the scaled canonical coefficients; and the innermost passes of both operands, the pointwise
+// product and the innermost pass of the inverse are one kernel:
+//
+//   k64_core_mul   chunk c of A and of B: 12 forward levels each, product, 12 inverse levels (transform lengths > 4096)
+//   k64_short_mul  whole products of transform length <= 4096, 4096 / length of them per workgroup
+//
 // Every kernel is a template over the field (Field64: Montgomery integers for p < 2^60; FieldD: exact
 // double-precision arithmetic for p <= 1.5e15, about four times fewer issue cycles per butterfly).
 //
