@@ -19,7 +19,9 @@ def poly_multiply(a, b, n, p):
 
 
 def poly_multiply_u64(a, b, n, p):
-    """64-bit entry point: direct NTT when p fits, four-prime CRT otherwise (main_naive.cc:253-257)."""
+    """64-bit entry point, the slot of the dispatch of main_naive.cc:253-257: the 32-bit NTT when p fits; for larger p the
+    residues the reference's four-prime CRT gives, computed in the field of p itself when p is an NTT-friendly prime
+    (the reference's 1337006139375617 is) and through the four primes otherwise -- see set_route_policy."""
     a = np.asarray(a, dtype=np.uint64)[:n]; b = np.asarray(b, dtype=np.uint64)[:n]
     return load_product_library().multiply_u64(a, b, p)
 
@@ -31,6 +33,12 @@ def poly_multiply_batched(a, b, p, n_gpus=0):
 
 def poly_multiply_batched_u64(a, b, p, n_gpus=0):
     return load_product_library().multiply_batched_u64(a, b, p, n_gpus)
+
+
+def set_route_policy(policy):
+    """'auto' (default: the fastest exact route) or 'reference' (the four-prime CRT wherever the reference uses it, i.e.
+    for every p > 2^32); returns the previous policy.  Results are identical either way."""
+    return load_product_library().set_route_policy(policy)
 
 
 # ---- text harness (main_naive.cc:13-67) ------------------------------------
