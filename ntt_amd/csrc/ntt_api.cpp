@@ -772,21 +772,27 @@ int transform64_f(const Plan64& pl, uint64_t* d, const Axis64& ax, bool inverse,
     return NTT_OK;
 }
 
-// The same with the outermost pass (first forward / last inverse) reading raw words from `src` or writing scaled
-// canonical results to `out` when that pass is a tile pass; returns false in *fused_io when it is not, and the caller
-// runs the separate load / finalize kernels instead.
-template <class F>
-int transform64_io(const Plan64& pl, uint64_t* d, const Axis64& ax, bool inverse, const TileExtra& io, bool* fused_io, hipStream_t st) {
+// Whether the outermost pass of a transform along `ax` (first forward / last inverse) can read raw caller words or write
+// scaled canonical results itself: the tiled and the register-only pass can, the contiguous-chunk passes cannot.
+bool outer_pass_takes_io(const Axis64& ax) {
+    if (ax.log_len <= 0) return false;
     const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer);
-    *fused_io = !steps.empty() && (steps.front().kind == Step64::TILE || steps.front().kind == Step64::REG);
+    return !steps.empty() && (steps.front().kind == Step64::TILE || steps.front().kind == Step64::REG);
+}
+
+// The transform with `io` (source of raw words, or destination and scale of the results) applied in its outermost pass;
+// only for axes for which outer_pass_takes_io() holds.
+template <class F>
+int transform64_io(const Plan64& pl, uint64_t* d, const Axis64& ax, bool inverse, const TileExtra& io, hipStream_t st) {
+    const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer);
     const TileExtra none;
     int rc;
     if (!inverse) {
         for (size_t i = 0; i < steps.size(); ++i)
-            if ((rc = run_step<F>(pl, d, steps[i], ax, false, (i == 0 && *fused_io) ? io : none, st)) != NTT_OK) return rc;
+            if ((rc = run_step<F>(pl, d, steps[i], ax, false, i == 0 ? io : none, st)) != NTT_OK) return rc;
     } else {
         for (size_t i = steps.size(); i-- > 0;)
-            if ((rc = run_step<F>(pl, d, steps[i], ax, true, (i == 0 && *fused_io) ? io : none, st)) != NTT_OK) return rc;
+            if ((rc = run_step<F>(pl, d, steps[i], ax, true, i == 0 ? io : none, st)) != NTT_OK) return rc;
     }
     return NTT_OK;
 }
@@ -807,6 +813,23 @@ int transform64(const Plan64& pl, uint64_t* d, int log_len, size_t inner, size_t
 // c = part * Cl + l (part < 2^log_parts, l < Cl = 2^(log_cols - log_parts)) of row r lives at
 // part * part_stride + r * Cl + l, r < rows.  Forward: one register pass over the parts (their twiddles depend on l
 // only), then plain transforms of length Cl on every (part, row); inverse: the mirror.
+// the register pass over the 2^log_parts parts of the split layout: `rows` rows of cl columns per part, parts
+// part_stride apart, twiddle index = position inside the part
+Pass64 parts_pass_geometry(const Plan64& pl, int log_cols, int log_parts, uint64_t part_stride, uint64_t rows) {
+    const uint64_t cl = (uint64_t)1 << (log_cols - log_parts);
+    Pass64 g{};
+    g.columns = rows * cl;
+    g.step = part_stride;
+    g.block_stride = 0;
+    g.n_blocks = 1;
+    g.q = log_parts;
+    g.hi_shift = 63;
+    g.lo_mask = cl - 1;
+    g.tw_stride = (uint64_t)1 << (pl.log_root - log_cols);
+    g.tw_mask = ((uint64_t)1 << pl.log_root) - 1;
+    return g;
+}
+
 int transform64_split(const Plan64& pl, uint64_t* d, int log_cols, int log_parts, uint64_t part_stride, uint64_t rows, bool inverse,
                       hipStream_t st) {
     if (log_parts < 0 || log_parts > 4 || log_parts > log_cols) return fail(NTT_ERR_ARG, "split layout supports 1 to 16 parts");
@@ -816,16 +839,7 @@ int transform64_split(const Plan64& pl, uint64_t* d, int log_cols, int log_parts
     const uint64_t cl = (uint64_t)1 << log_cl;
     auto parts_pass = [&]() -> int {
         if (log_parts == 0) return NTT_OK;
-        Pass64 g{};
-        g.columns = rows * cl;
-        g.step = part_stride;
-        g.block_stride = 0;
-        g.n_blocks = 1;
-        g.q = log_parts;
-        g.hi_shift = 63;
-        g.lo_mask = cl - 1;            // jq = l: the position inside the part
-        g.tw_stride = (uint64_t)1 << (pl.log_root - log_cols);
-        g.tw_mask = ((uint64_t)1 << pl.log_root) - 1;
+        const Pass64 g = parts_pass_geometry(pl, log_cols, log_parts, part_stride, rows);
         const TileExtra none;
         return pl.fp ? launch_pass<FieldD>(pl, d, false, g, inverse, none, st) : launch_pass<Field64>(pl, d, false, g, inverse, none, st);
     };
@@ -866,17 +880,7 @@ int product64_split_f(const Plan64& pl, uint64_t* a, uint64_t* b, int log_cols, 
     int rc;
     auto parts_pass = [&](uint64_t* d, bool inverse) -> int {
         if (log_parts == 0) return NTT_OK;
-        Pass64 g{};
-        g.columns = rows * cl;
-        g.step = part_stride;
-        g.block_stride = 0;
-        g.n_blocks = 1;
-        g.q = log_parts;
-        g.hi_shift = 63;
-        g.lo_mask = cl - 1;
-        g.tw_stride = (uint64_t)1 << (pl.log_root - log_cols);
-        g.tw_mask = ((uint64_t)1 << pl.log_root) - 1;
-        return launch_pass<F>(pl, d, false, g, inverse, none, st);
+        return launch_pass<F>(pl, d, false, parts_pass_geometry(pl, log_cols, log_parts, part_stride, rows), inverse, none, st);
     };
     if ((rc = parts_pass(a, false)) != NTT_OK || (rc = parts_pass(b, false)) != NTT_OK) return rc;
     Axis64 ax;
@@ -1816,18 +1820,13 @@ int ntt64_fourstep_rows_load_device(const uint64_t* d_src, size_t rows_valid, ui
     TileExtra io;
     io.src = d_src;
     io.src_valid = (uint64_t)rows_valid * cols_local;   // row-major slab: the rows below rows_valid are its first elements
-    bool fused = false;
-    if (log_rows > 0) {
-        const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer);
-        fused = !steps.empty() && (steps.front().kind == Step64::TILE || steps.front().kind == Step64::REG);
-    }
-    if (!fused) {
+    if (!outer_pass_takes_io(ax)) {
         load64(*pl, d_src, 0, io.src_valid, d_slab, rows * cols_local, 1, st);
         HIP_TRY(hipGetLastError());
         if (log_rows == 0) return NTT_OK;
         return transform64_axis(*pl, d_slab, ax, false, st);
     }
-    return pl->fp ? transform64_io<FieldD>(*pl, d_slab, ax, false, io, &fused, st) : transform64_io<Field64>(*pl, d_slab, ax, false, io, &fused, st);
+    return pl->fp ? transform64_io<FieldD>(*pl, d_slab, ax, false, io, st) : transform64_io<Field64>(*pl, d_slab, ax, false, io, st);
 }
 
 int ntt64_fourstep_rows_store_device(uint64_t* d_slab, uint64_t* d_out, uint64_t p, int log_total, int log_rows, size_t cols_local,
@@ -1842,12 +1841,7 @@ int ntt64_fourstep_rows_store_device(uint64_t* d_slab, uint64_t* d_out, uint64_t
     hipStream_t st = (hipStream_t)stream;
     const uint64_t Linv = h_powmod((1ull << log_total) % p, p - 2, p);
     const uint64_t scale = h_mulmod(Linv, pointwise_compensation(*pl), p);
-    bool fused = false;
-    if (log_rows > 0) {
-        const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer);
-        fused = !steps.empty() && (steps.front().kind == Step64::TILE || steps.front().kind == Step64::REG);
-    }
-    if (!fused) {
+    if (!outer_pass_takes_io(ax)) {
         if (log_rows > 0 && (rc = transform64_axis(*pl, d_slab, ax, true, st)) != NTT_OK) return rc;
         finalize64(*pl, d_slab, count, d_out, 0, count, 1, scale, st);
         HIP_TRY(hipGetLastError());
@@ -1857,7 +1851,7 @@ int ntt64_fourstep_rows_store_device(uint64_t* d_slab, uint64_t* d_out, uint64_t
     io.out = d_out;
     io.n_out = count;
     io.scale_word = tw_word(*pl, scale);
-    return pl->fp ? transform64_io<FieldD>(*pl, d_slab, ax, true, io, &fused, st) : transform64_io<Field64>(*pl, d_slab, ax, true, io, &fused, st);
+    return pl->fp ? transform64_io<FieldD>(*pl, d_slab, ax, true, io, st) : transform64_io<Field64>(*pl, d_slab, ax, true, io, st);
 }
 
 int ntt64_fourstep_cols_product_device(uint64_t* d_a_rows, uint64_t* d_b_rows, uint64_t p, int log_total, int log_cols, int log_parts,
