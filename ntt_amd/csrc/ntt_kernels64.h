@@ -212,6 +212,11 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
     const uint64_t origin = blk_g * g.block_stride + col;       // element offset of row 0 of this column
     const uint64_t jq = pass_jq(g, col);
     const int ql = ((q - 1) & 3) + 1;                           // levels of the last (smallest) round, 1..4
+    // LDS slot of (row, this thread's column).  64-bit LDS accesses are served 32 lanes at a time: with 16 columns per
+    // row two rows share an access, and in the rounds whose rows lie 16 apart they would land on the same banks, so
+    // row bit 4 is folded into slot bit 4 there.
+    const int fold = logW == 4 ? 1 : 0;
+    auto tile_slot = [&](int row) -> int { return ((row << logW) + x) ^ ((((row >> 4) & 1) & fold) << 4); };
     V v[16];
 
     // Pass twiddles of the 16 rows 16*grp + i that a thread holds in the last forward / first inverse round: row r holds
@@ -256,20 +261,20 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
                 }
             } else {
 #pragma unroll
-                for (int m = 0; m < 16; ++m) v[m] = lds[((row0 + m * sub) << logW) + x];
+                for (int m = 0; m < 16; ++m) v[m] = lds[tile_slot(row0 + m * sub)];
             }
             NTT_MATH64(dif_blocks<F, 4, true>(v, f, rF); v[0] = f.settle(v[0]));
             const uint64_t* T = rt.f[b] + ((size_t)j << 4);
 #pragma unroll
             for (int pos = 1; pos < 16; ++pos) NTT_MATH64(v[pos] = f.twiddled(v[pos], f.tw_from_mem(T[pos])));
 #pragma unroll
-            for (int m = 0; m < 16; ++m) lds[((row0 + m * sub) << logW) + x] = v[m];
+            for (int m = 0; m < 16; ++m) lds[tile_slot(row0 + m * sub)] = v[m];
             __syncthreads();
             first = false;
         }
         // last round: rows 16*grp + i, blocks of 2^ql rows; then the pass twiddle and the store
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = lds[(((grp << 4) + i) << logW) + x];
+        for (int i = 0; i < 16; ++i) v[i] = lds[tile_slot((grp << 4) + i)];
         NTT_MATH64(dif_blocks_rt<F>(ql, v, f, rF));
         uint64_t idx = origin + (uint64_t)(grp << 4) * step;
         static_for<0, 16>([&](auto I) {
@@ -285,7 +290,7 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
         static_for<0, 16>([&](auto I) { constexpr int i = decltype(I)::value; NTT_MATH64(v[i] = f.twiddled(v[i], pass_twiddle(I))); });
         NTT_MATH64(dit_blocks_rt<F, true>(ql, v, f, rI));
 #pragma unroll
-        for (int i = 0; i < 16; ++i) lds[(((grp << 4) + i) << logW) + x] = v[i];
+        for (int i = 0; i < 16; ++i) lds[tile_slot((grp << 4) + i)] = v[i];
         __syncthreads();
         for (int b = ql + 4; b <= q; b += 4) {
             const int sub = 1 << (b - 4);
@@ -294,14 +299,14 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
             const uint64_t* T = rt.i[b] + ((size_t)j << 4);
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
-                const V r = lds[((row0 + m * sub) << logW) + x];
+                const V r = lds[tile_slot(row0 + m * sub)];
                 v[m] = r;
                 NTT_MATH64(v[m] = m ? f.twiddled(r, f.tw_from_mem(T[m])) : f.settle(r));
             }
             NTT_MATH64(dit_blocks<F, 4, true>(v, f, rI));
             if (b < q) {
 #pragma unroll
-                for (int m = 0; m < 16; ++m) lds[((row0 + m * sub) << logW) + x] = v[m];
+                for (int m = 0; m < 16; ++m) lds[tile_slot(row0 + m * sub)] = v[m];
                 __syncthreads();
             } else {
                 uint64_t o = origin + (uint64_t)row0 * step;
@@ -323,12 +328,14 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
 
 // ---------------------------------------------------------------------------
 // k64_local: chunks of 4096 consecutive values holding 4096 >> m complete blocks of 2^m values each (m = 1..12);
-// all m levels inside LDS.  LDS slot of element e is e ^ ((e >> 4) & 15), which keeps the three access patterns
-// (copy in/out by consecutive threads, rounds with a stride of 2^(b-4), 16 consecutive values per thread) spread
-// over all banks.  MUL (inverse only): the chunk starts as the pointwise product of `data` and `other`.
+// all m levels inside LDS.  LDS slot of element e is e with bits 4-7 XORed into bits 0-3 and bit 8 into bit 4, which
+// gives every group of 32 consecutive lanes 32 different 8-byte slots modulo 32 in the three access patterns of a
+// full chunk (copy in/out by consecutive threads, rounds with a stride of 256 and of 16, 16 consecutive values per
+// thread): 64-bit LDS accesses are served 32 lanes at a time.
+// MUL (inverse only): the chunk starts as the pointwise product of `data` and `other`.
 // FINAL (inverse only): multiply by `scale`, canonical, elements below n_out to `out`.
 // ---------------------------------------------------------------------------
-NTT_HD int local_slot(int e) { return e ^ ((e >> 4) & 15); }
+NTT_HD int local_slot(int e) { return e ^ ((e >> 4) & 15) ^ (((e >> 8) & 1) << 4); }
 
 template <class F, bool INVERSE, bool MUL, bool FINAL>
 __global__ void __launch_bounds__(LOCAL64_T) k64_local(uint64_t* data, const uint64_t* other, uint64_t* out, uint64_t n_out,
