@@ -19,6 +19,13 @@
 
 #include "ntt_field.h"
 
+// The double-precision field below is exact integer arithmetic: every product, sum and fused multiply-add is written out
+// and must be executed as written.  Contraction of a multiply and an add into one fused operation (hipcc's default for
+// device code) changes roundings; the build passes -ffp-contract=off, and this says the same for any other build line.
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
 namespace nttamd {
 
 NTT_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
