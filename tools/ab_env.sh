@@ -9,7 +9,7 @@ for round in 1 2 3; do
   i=0
   for v in "$@"; do
     echo "## variant $i [$v] round $round" >> $out
-    env $v timeout -k 10 120 python3 bench.py $bargs --no-cpu-baseline >> $out 2>&1 || { echo "variant failed: $v"; tail -5 $out; exit 1; }
+    env $v timeout -k 10 120 python3 bench.py $bargs --no-cpu-baseline --no-other-configs >> $out 2>&1 || { echo "variant failed: $v"; tail -5 $out; exit 1; }
     i=$((i+1))
   done
 done

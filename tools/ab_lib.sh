@@ -9,7 +9,7 @@ for round in 1 2 3; do
   for v in "$@"; do
     echo "## variant [$v] round $round" >> $out
     if [ "$v" = shipped ]; then la=""; else la="--lib $v --no-verify"; fi
-    timeout -k 10 120 python3 bench.py $bargs $la --no-cpu-baseline >> $out 2>&1 || { echo "variant failed: $v"; tail -5 $out; exit 1; }
+    timeout -k 10 120 python3 bench.py $bargs $la --no-cpu-baseline --no-other-configs >> $out 2>&1 || { echo "variant failed: $v"; tail -5 $out; exit 1; }
   done
 done
 python3 - <<PY

@@ -9,7 +9,7 @@ for lib in "${libs[@]}"; do
   out=$PWD/gpurun_out/clock_$name
   mkdir -p "$out"
   if [ "$lib" = shipped ]; then la=""; else la="--lib $lib --no-verify"; fi
-  timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out" -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-events $la > "$out/run.log" 2>&1 || { echo "failed: $lib"; tail -5 "$out/run.log"; exit 1; }
+  timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out" -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-events --no-other-configs $la > "$out/run.log" 2>&1 || { echo "failed: $lib"; tail -5 "$out/run.log"; exit 1; }
   python3 - "$out" "$name" <<'PY'
 import csv, glob, sys, collections, re
 out, name = sys.argv[1], sys.argv[2]

@@ -8,8 +8,8 @@ out=$PWD/gpurun_out/prof_$tag
 mkdir -p "$out"
 # the trace run keeps the benchmark's clock ramp (so its per-kernel averages are steady-state ones, like the
 # benchmark's own); the counter passes do not need it
-args="--steps 5 --warmup 2 --ramp-ms 0 --no-cpu-baseline --no-kernel-events $*"
-targs="--steps 100 --warmup 10 --no-cpu-baseline --no-kernel-events $*"
+args="--steps 5 --warmup 2 --ramp-ms 0 --no-cpu-baseline --no-kernel-events --no-other-configs $*"
+targs="--steps 100 --warmup 10 --no-cpu-baseline --no-kernel-events --no-other-configs $*"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py $targs > "$out/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$out/trace.log"; exit 1; }
 timeout -s KILL 240 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d "$out/pmc_sq" -- python3 bench.py $args > "$out/pmc_sq.log" 2>&1 || { echo "pmc sq failed"; tail -5 "$out/pmc_sq.log"; exit 1; }
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py $args > "$out/pmc_fetch.log" 2>&1 || { echo "pmc fetch failed"; tail -5 "$out/pmc_fetch.log"; exit 1; }

@@ -5,7 +5,7 @@ tag=${1:-r01}
 out=gpurun_out/sweep_$tag.txt
 : > $out
 for b in 8 16 32 64 128 256 512; do
-  timeout -k 10 120 python3 bench.py --batch $b --steps 20 --warmup 3 --no-cpu-baseline >> $out 2>&1 || exit 1
+  timeout -k 10 120 python3 bench.py --batch $b --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs >> $out 2>&1 || exit 1
 done
 python3 - <<PY
 import json
