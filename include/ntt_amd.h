@@ -14,7 +14,7 @@
  * four fixed 31-bit NTT primes and a 128-bit CRT merge (the reference's route,
  * main_naive.cc:178-230).  Sizes and moduli beyond that basis (n*(p-1)^2 >= 2^118.9
  * or transform lengths above 2^18) are computed in the 64-bit field of p itself when
- * p is NTT-friendly, and otherwise through two or three 59-bit NTT primes with a
+ * p is NTT-friendly, and otherwise through two or three 50- or 59-bit NTT primes with a
  * Garner recombination: every modulus 2 <= p < 2^64 is served.
  *
  * One caller at a time per process (the reference is single-threaded at this

@@ -1037,19 +1037,19 @@ int field64_product_device(Device* dev, const uint64_t* a, const uint64_t* b, ui
 
 size_t wide_crt_workspace_bytes(size_t n, uint64_t p, size_t batch) {
     const int logL = ceil_log2(2 * (uint64_t)n - 1) < 1 ? 1 : ceil_log2(2 * (uint64_t)n - 1);
-    const size_t k = (size_t)wide_crt_primes_needed(n, p);
+    const size_t k = (size_t)wide_crt_basis(n, p, fieldd_allowed()).k;
     return field64_workspace_bytes(logL, batch) + k * batch * (2 * n - 1) * sizeof(uint64_t);
 }
 
-int make_wide_crt_consts(uint64_t p, int k, WideCrtConsts* c) {
-    c->k = k;
+int make_wide_crt_consts(uint64_t p, const WideBasis& basis, WideCrtConsts* c) {
+    c->k = basis.k;
     for (int i = 0; i < 3; ++i) {
-        const uint64_t q = kWidePrimes[i];
+        const uint64_t q = basis.q[i];
         uint64_t inv = q;
         for (int it = 0; it < 6; ++it) inv *= 2 - q * inv;
         c->q[i] = q; c->nq[i] = 0 - inv;
     }
-    const uint64_t q1 = kWidePrimes[0], q2 = kWidePrimes[1], q3 = kWidePrimes[2];
+    const uint64_t q1 = basis.q[0], q2 = basis.q[1], q3 = basis.q[2];
     c->inv1_m2 = h_mont64(h_powmod(q1 % q2, q2 - 2, q2), q2);
     c->inv1_m3 = h_mont64(h_powmod(q1 % q3, q3 - 2, q3), q3);
     c->inv2_m3 = h_mont64(h_powmod(q2 % q3, q3 - 2, q3), q3);
@@ -1065,7 +1065,8 @@ int make_wide_crt_consts(uint64_t p, int k, WideCrtConsts* c) {
 // Any modulus below 2^64, transform lengths up to 2^32: one 64-bit-field product per wide prime, then Garner.
 int wide_crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, uint64_t p, size_t batch,
                             size_t sa, size_t sb, size_t so, void* ws, size_t ws_bytes, hipStream_t st) {
-    const int k = wide_crt_primes_needed(n, p);
+    const WideBasis basis = wide_crt_basis(n, p, fieldd_allowed());
+    const int k = basis.k;
     if (k == 0 || p < 2) return fail(NTT_ERR_MODULUS, "n*(p-1)^2 exceeds the product of the three wide CRT primes");
     const size_t need = wide_crt_workspace_bytes(n, p, batch);
     if (ws) {
@@ -1078,11 +1079,11 @@ int wide_crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, u
     uint64_t* res = (uint64_t*)((char*)ws + field_ws);
     const size_t count = 2 * n - 1, res_stride = batch * count;
     for (int i = 0; i < k; ++i) {
-        int rc = field64_product_device(dev, a, b, res + (size_t)i * res_stride, n, kWidePrimes[i], batch, sa, sb, count, ws, field_ws, st);
+        int rc = field64_product_device(dev, a, b, res + (size_t)i * res_stride, n, basis.q[i], batch, sa, sb, count, ws, field_ws, st);
         if (rc != NTT_OK) return rc;
     }
     WideCrtConsts c;
-    int rc = make_wide_crt_consts(p, k, &c);
+    int rc = make_wide_crt_consts(p, basis, &c);
     if (rc != NTT_OK) return rc;
     NTT_LAUNCH_P("k64_garner", k64_garner, dim3((unsigned)((count + 255) / 256), grid_rows(batch)), dim3(256), st, (const uint64_t*)res,
                  res_stride, out, count, batch, so, count, c);
@@ -1097,7 +1098,8 @@ int wide_crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, u
 //                  twelve of 32-bit ones plus the merge); skipped under NTT_ROUTE_REFERENCE
 //   four-prime CRT any p with n*(p-1)^2 below the product of the primes, L <= 2^18 (the reference's route for p > 2^32)
 //   64-bit field   p < 2^60 with L | p-1: lengths and moduli beyond the above, integer Montgomery arithmetic
-//   wide CRT       everything else up to L = 2^32: two or three 59-bit NTT primes, Garner recombination
+//   wide CRT       everything else up to L = 2^32: two or three NTT primes of 50 bits (double-precision field) or 59 bits
+//                  (integer field), whichever basis needs fewer transforms' worth of work; Garner recombination
 enum Route { ROUTE_DIRECT32, ROUTE_CRT, ROUTE_FIELD64, ROUTE_WIDECRT, ROUTE_NONE };
 constexpr int MAX_LOG_L32 = 18;
 std::atomic<int> g_route_policy{NTT_ROUTE_AUTO};
@@ -1113,7 +1115,7 @@ Route choose_route(uint64_t p, size_t n, std::string* why) {
         return ROUTE_FIELD64;
     if (crt) return ROUTE_CRT;
     if (modulus64_ok(p, logL, &w64)) return ROUTE_FIELD64;
-    if (p >= 2 && logL <= 32 && wide_crt_primes_needed(n, p) != 0) return ROUTE_WIDECRT;
+    if (p >= 2 && logL <= 32 && wide_crt_basis(n, p, fieldd_allowed()).k != 0) return ROUTE_WIDECRT;
     if (why) *why = "no exact route for this modulus and length: the four-prime CRT needs n*(p-1)^2 < 2^118.9 and length <= 2^18; "
                     "the 64-bit field needs " + w64;
     return ROUTE_NONE;

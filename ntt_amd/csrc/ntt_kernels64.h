@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(256) k64_finalize(const uint64_t* data, uint64
 }
 
 // ---------------------------------------------------------------------------
-// k64_garner: recombination of residues modulo two or three 59-bit NTT primes into the product coefficient
+// k64_garner: recombination of residues modulo two or three NTT primes of like size (59 or 50 bits) into the product coefficient
 // modulo an arbitrary 64-bit p (mixed-radix / Garner form, all arithmetic in 64-bit words):
 //   x = t1 + q1*(t2 + q2*t3),  t1 = r1,  t2 = (r2 - t1)/q1 mod q2,  t3 = ((r3 - t1)/q1 - t2)/q2 mod q3,
 //   out = (t1 + (q1 mod p)*t2 + (q1*q2 mod p)*t3) mod p.

@@ -253,13 +253,24 @@ inline int bit_length(uint64_t x) {
     while (x) { ++b; x >>= 1; }
     return b;
 }
-// primes needed so that every coefficient n*(p-1)^2 of the integer product stays below their product
-// (q1*q2 > 2^117, q1*q2*q3 > 2^176); 0 = not even three suffice
-inline int wide_crt_primes_needed(uint64_t n, uint64_t p) {
+// The same for the double-precision flavour of the 64-bit field (primes below 1.5e15, 50.4 bits each): a product in it
+// costs about two thirds of one in Montgomery integers, so this basis is taken wherever it needs no more primes.
+static const uint64_t kWidePrimesD[3] = {1499510521987073ull, 1499458982379521ull, 1499407442771969ull};
+
+// Basis and number of primes such that every coefficient of the integer product, at most n*(p-1)^2 < 2^bits, stays
+// below their product (59-bit primes: q1*q2 > 2^117, q1*q2*q3 > 2^176; 50-bit primes: > 2^100 and > 2^151).
+// k = 0: not even three 59-bit primes suffice.
+struct WideBasis {
+    const uint64_t* q;
+    int k;
+};
+inline WideBasis wide_crt_basis(uint64_t n, uint64_t p, bool double_precision_ok) {
     const int bits = bit_length(n) + 2 * bit_length(p - 1);
-    if (bits <= 117) return 2;
-    if (bits <= 176) return 3;
-    return 0;
+    if (double_precision_ok && bits <= 100) return {kWidePrimesD, 2};
+    if (bits <= 117) return {kWidePrimes, 2};
+    if (double_precision_ok && bits <= 151) return {kWidePrimesD, 3};
+    if (bits <= 176) return {kWidePrimes, 3};
+    return {nullptr, 0};
 }
 
 }  // namespace nttamd

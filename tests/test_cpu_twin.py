@@ -298,10 +298,11 @@ def test_transform_along_a_strided_axis_tiled_and_register_passes(twin, oracle):
 
 
 def test_wide_crt_route_any_modulus(twin, oracle):
-    """Moduli and sizes that neither the four 31-bit primes nor the modulus itself can carry: two or three 59-bit
-    primes and Garner recombination.  Checked against the schoolbook product in 128-bit arithmetic."""
+    """Moduli and sizes that neither the four 31-bit primes nor the modulus itself can carry: two or three primes of 50
+    bits (double-precision field: needs n*(p-1)^2 below 2^100 resp. 2^151) or of 59 bits (integer field: 2^117, 2^176) and
+    Garner recombination.  Checked against the schoolbook product in 128-bit arithmetic."""
     rng = np.random.default_rng(59)
-    cases = [(2**64 - 59, 300),            # largest 64-bit prime: three primes
+    cases = [(2**64 - 59, 300),            # largest 64-bit prime: three 50-bit primes
              (2**63 + 29, 64), (2**62 - 57, 1000),
              (2**61 - 1, 257),             # above the 64-bit field's limit
              (10**18 + 9, 100), (2**64 - 1, 50), (2**64 - 2**32, 33),   # composite and even moduli
@@ -315,19 +316,52 @@ def test_wide_crt_route_any_modulus(twin, oracle):
     p, n = 2**64 - 59, 512
     a = np.full(n, p - 1, dtype=np.uint64)
     assert np.array_equal(twin.multiply_u64(a, a, p), oracle.schoolbook_u64(a, a, p))
-    # two primes suffice for a 50-bit modulus that is not NTT-friendly at a length above 2^18
-    p, n = 1337006139375617 + 2, 1 << 18     # odd, not of the form c*2^k+1 for large k
-    a = rng.integers(0, p, n, dtype=np.uint64)
-    e = np.zeros(n, dtype=np.uint64); e[3] = 2
-    got = twin.multiply_u64(a, e, p)
-    assert twin.describe_plan(n, p).endswith("k64_garner")
-    assert np.array_equal(got[3:3 + n], (a.astype(object) * 2 % p).astype(np.uint64)) and not got[:3].any()
+    # lengths above 2^18 with moduli that are not NTT-friendly: 121 bits -> three 50-bit primes; 115 bits -> two 59-bit
+    # primes (three 50-bit ones would be more work); 85 bits -> two 50-bit primes
+    for p in (1337006139375617 + 2, 2**47 + 5, 4294967311):
+        n = 1 << 18
+        a = rng.integers(0, p, n, dtype=np.uint64)
+        e = np.zeros(n, dtype=np.uint64); e[3] = 2
+        got = twin.multiply_u64(a, e, p)
+        assert twin.describe_plan(n, p).endswith("k64_garner")
+        assert np.array_equal(got[3:3 + n], (a.astype(object) * 2 % p).astype(np.uint64)) and not got[:3].any(), p
     # batched rows
     p, n = 2**63 + 29, 40
     ab = rng.integers(0, p, (3, n), dtype=np.uint64); bb = rng.integers(0, p, (3, n), dtype=np.uint64)
     got = twin.multiply_batched_u64(ab, bb, p)
     for r in range(3):
         assert np.array_equal(got[r], oracle.schoolbook_u64(ab[r], bb[r], p))
+
+
+WIDE_INT_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from ntt_amd._binding import NttLibrary
+from oracle_binding import Oracle
+lib = NttLibrary(LIB); orc = Oracle()
+rng = np.random.default_rng(176)
+ok = True
+for p, n in ((2**64 - 59, 300), (2**63 + 29, 64), (1000000007, 3000), (2**64 - 1, 50)):
+    a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
+    a[0] = p - 1; b[-1] = p - 1
+    ok = ok and lib.describe_plan(n, p).endswith("k64_garner" if p > 2**32 else "k_crt_merge")
+    ok = ok and np.array_equal(lib.multiply_u64(a, b, p), orc.schoolbook_u64(a, b, p))
+print("RESULT", ok)
+'''
+
+
+def test_wide_crt_route_on_the_integer_basis(twin, tmp_path):
+    """NTT_FIELD64=int keeps every product on Montgomery integers, so the same moduli go through the 59-bit primes
+    (three of them for the 64-bit moduli: 137 bits)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "wide_int.py"
+    script.write_text(f"ROOT = {root!r}\nLIB = {twin.path!r}\n" + WIDE_INT_WORKER)
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, NTT_FIELD64="int"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RESULT True" in r.stdout, r.stdout[-500:]
 
 
 def check_lifecycle_and_argument_errors(lib, oracle):
