@@ -247,6 +247,19 @@ def test_wide_crt_route_any_modulus(gpu_lib, oracle):
     assert int(got[2 * n - 2]) == int(a[-1]) * int(b[-1]) % p
 
 
+def test_wide_crt_route_on_the_integer_basis(gpu_lib, tmp_path):
+    """The same moduli with NTT_FIELD64=int (fresh process): every product in Montgomery integers, 59-bit primes."""
+    import subprocess
+    import sys
+    from test_cpu_twin import WIDE_INT_WORKER
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "wide_int.py"
+    script.write_text(f"ROOT = {root!r}\nLIB = {gpu_lib.path!r}\n" + WIDE_INT_WORKER)
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, NTT_FIELD64="int"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RESULT True" in r.stdout, r.stdout[-500:]
+
+
 def test_lifecycle_and_argument_errors(gpu_lib, oracle):
     from test_cpu_twin import check_lifecycle_and_argument_errors
     check_lifecycle_and_argument_errors(gpu_lib, oracle)
