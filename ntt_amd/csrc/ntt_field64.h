@@ -206,7 +206,7 @@ struct FieldD {
     NTT_HD uint64_t to_mem(double x) const { return double_to_bits(reduce(x) + (TWO52 + p)) & 0x000FFFFFFFFFFFFFull; }
     NTT_HD double tw_from_mem(uint64_t raw) const { return bits_to_double(raw); }   // tables hold balanced doubles
     NTT_HD double twmul(double a, double b) const { return mulw(a, b); }             // |a|, |b| <= p/2 -> |r| <= 0.57 p
-    NTT_HD double mulpw(double a, double b) const { return mulw(reduce(a), reduce(b)); }
+    NTT_HD double mulpw(double a, double b) const { return mulw(reduce(a), b); }       // |b| <= 2.5 p: one reduced factor suffices
     NTT_HD double twiddled(double x, double w) const { return mulw(x, w); }          // |x| <= 2.5 p
     NTT_HD uint64_t canon(double x) const {
         double r = reduce(x);

@@ -70,6 +70,9 @@ int main(int argc, char** argv) {
             if (!congruent(u, eu, p) || !congruent(v, ev, p) || fabs(u) > 1.75 * (double)p + 3 || fabs(v) > 1.75 * (double)p + 3) {
                 printf("dit p=%lld\n", (long long)p); return 1;
             }
+            // pointwise product: any held value times a value up to 2.5 p
+            const double pw = f.mulpw((double)y, (double)x);
+            if (!congruent(pw, (i128)y * x, p) || fabs(pw) > 1.25 * (double)p + 2) { printf("mulpw p=%lld\n", (long long)p); return 1; }
             // arbitrary 64-bit words in, canonical words out
             const uint64_t raw = (s & 15) == 2 ? ~(uint64_t)0 - (uint64_t)(s >> 4) % 3 : rnd();
             const double fr = f.from_raw(raw);
