@@ -38,6 +38,14 @@ struct FieldConsts {
     uint32_t rootI[32];   // Montgomery form of  w64^-e
 };
 
+// makes a per-thread value opaque to the optimiser, so that the indices, row numbers and masks derived from it are
+// recomputed where they are used instead of being kept in registers across the whole kernel
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NTT_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define NTT_OPAQUE(x) asm volatile("" : "+r"(x))
+#endif
+
 // (T + m*p) / 2^32 with m = T*np mod 2^32.  For T < 2^32 * p the result is in [0, 2p).
 NTT_HD uint32_t redc_lazy(uint64_t T, uint32_t p, uint32_t np) {
     uint32_t m = (uint32_t)T * np;

@@ -503,7 +503,8 @@ __global__ void __launch_bounds__(CORE_T) k_small16(const TIn* A, const TIn* Bp,
     // operands -> LDS, zero padded (values beyond n, products beyond the batch)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int e = t + CORE_T * i;
+        int e = t + CORE_T * i;
+        NTT_OPAQUE(e);          // or sixteen sets of product number / index / slot stay in registers until the final store
         const size_t prod = first + (size_t)(e >> logL);
         const int idx = e & ((1 << logL) - 1);
         const bool inside = prod < batch && idx < n;
@@ -571,7 +572,8 @@ __global__ void __launch_bounds__(CORE_T) k_small16(const TIn* A, const TIn* Bp,
     // scale by L^-1 (and the factor the pointwise product left), canonical, first 2n-1 coefficients of every product
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int e = t + CORE_T * i;
+        int e = t + CORE_T * i;
+        NTT_OPAQUE(e);
         const size_t prod = first + (size_t)(e >> logL);
         const int idx = e & ((1 << logL) - 1);
         if (prod < batch && idx < n_out) out[prod * out_stride + idx] = (TOut)f.canon_fwd(f.mulw(la[small_slot(e)], scale_m));

@@ -82,13 +82,6 @@ struct Pass64 {
 // compiler-only barrier: keeps the loads of a later phase from being hoisted over the arithmetic of an earlier one (the
 // registers they would occupy cost more in occupancy than the early issue gains)
 #define NTT_FENCE64() asm volatile("" ::: "memory")
-// makes a per-thread value opaque to the optimiser, so that the indices, row numbers and masks derived from it are
-// recomputed where they are used instead of being kept in registers across the whole kernel
-#if defined(__HIP_DEVICE_COMPILE__)
-#define NTT_OPAQUE(x) asm volatile("" : "+v"(x))
-#else
-#define NTT_OPAQUE(x) asm volatile("" : "+r"(x))
-#endif
 
 #ifdef NTT_ABLATE64_MATH
 #define NTT_MATH64(...)
