@@ -17,8 +17,11 @@
  * p is NTT-friendly, and otherwise through two or three 50- or 59-bit NTT primes with a
  * Garner recombination: every modulus 2 <= p < 2^64 is served.
  *
- * One caller at a time per process (the reference is single-threaded at this
- * boundary too); calls on different devices may not overlap.
+ * Threads: every entry point takes one library-wide lock, so concurrent callers are
+ * serialised, not refused (the reference is single-threaded at this boundary).  The
+ * device-pointer entry points only enqueue work: it is ordered on the stream they are
+ * given, and work enqueued on different streams or devices may overlap on the hardware.
+ * A multi-device host call runs one host thread per device inside the library.
  */
 #ifndef NTT_AMD_H
 #define NTT_AMD_H
@@ -46,6 +49,13 @@ void ntt_shutdown(void);
 int ntt_device_count(void);
 /* message for the last non-zero status on this thread ("" if none) */
 const char *ntt_last_error(void);
+/* Device-pointer calls given workspace == NULL use a workspace the library owns: one per stream, on the current device,
+ * grown to the largest call seen and kept until ntt_shutdown (one n = 2^28 product pins 8 GiB) -- the static pools of the
+ * reference's threaded programs (main_pthread.cc:270-273) are the same idea.  At most 8 streams per device keep one; a
+ * ninth takes the place of the least recently used (after a device-wide wait).  ntt_release_workspace frees the one of
+ * `stream` after waiting for that stream, or, with all_streams != 0, every one of the current device after waiting for
+ * the device.  Call it before destroying a stream whose handle may be reused. */
+int ntt_release_workspace(void *stream, int all_streams);
 
 /* How a modulus above 2^31 is served.  The reference splits every such product over four 32-bit NTT primes and merges
  * the residues with 128-bit arithmetic (CRT_NTT_multiply_serial, main_naive.cc:178-230).  Its one large modulus,

@@ -19,7 +19,7 @@ c_u64p = ctypes.POINTER(ctypes.c_uint64)
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 
 EXPORTS = [
-    "ntt_init", "ntt_shutdown", "ntt_device_count", "ntt_last_error", "ntt_set_route_policy",
+    "ntt_init", "ntt_shutdown", "ntt_device_count", "ntt_last_error", "ntt_set_route_policy", "ntt_release_workspace",
     "poly_multiply", "poly_multiply_u64", "ntt_poly_multiply_i32", "ntt_poly_multiply_u64",
     "ntt_poly_multiply_batched", "ntt_poly_multiply_batched_u64",
     "ntt_workspace_bytes", "ntt_poly_multiply_batched_device", "ntt_poly_multiply_batched_device_u64",
@@ -56,6 +56,7 @@ class NttLibrary:
         L.ntt_shutdown.argtypes = []; L.ntt_shutdown.restype = None
         L.ntt_device_count.argtypes = []; L.ntt_device_count.restype = ctypes.c_int
         L.ntt_last_error.argtypes = []; L.ntt_last_error.restype = ctypes.c_char_p
+        L.ntt_release_workspace.argtypes = [ctypes.c_void_p, ctypes.c_int]; L.ntt_release_workspace.restype = ctypes.c_int
         L.poly_multiply.argtypes = [c_i32p, c_i32p, c_i32p, ctypes.c_int, ctypes.c_int]; L.poly_multiply.restype = None
         L.poly_multiply_u64.argtypes = [c_u64p, c_u64p, c_u64p, ctypes.c_int, ctypes.c_uint64]; L.poly_multiply_u64.restype = None
         L.ntt_poly_multiply_i32.argtypes = [c_i32p, c_i32p, c_i32p, ctypes.c_int, ctypes.c_int]; L.ntt_poly_multiply_i32.restype = ctypes.c_int

@@ -134,12 +134,30 @@ struct Device {
     std::map<std::pair<uint64_t, int>, std::unique_ptr<struct Plan64>> plans64;
     // library-owned workspaces, one per stream the NULL-workspace calls were enqueued on: calls on different streams may
     // overlap on the device, so they must not share scratch memory.  A buffer only ever grows; growing frees the old
-    // one with hipFree, which waits for the device first, so nothing in flight loses its memory.
-    std::map<hipStream_t, DevBuf> work;
+    // one with hipFree, which waits for the device first, so nothing in flight loses its memory.  At most
+    // MAX_STREAM_WORKSPACES streams keep one: a further stream takes over the least recently used entry's place (after
+    // a device-wide wait -- the stream it belonged to may no longer exist, so it cannot be waited for by handle), and
+    // ntt_release_workspace() frees them on request.
+    static constexpr size_t MAX_STREAM_WORKSPACES = 8;
+    struct StreamWork { DevBuf buf; uint64_t last_use = 0; };
+    std::map<hipStream_t, StreamWork> work;
+    uint64_t work_clock = 0;
     int workspace_for(hipStream_t st, size_t need, void** ws) {
-        DevBuf& b = work[st];
-        int rc = b.ensure(need);
-        if (rc == NTT_OK) *ws = b.ptr;
+        auto it = work.find(st);
+        if (it == work.end()) {
+            if (work.size() >= MAX_STREAM_WORKSPACES) {
+                auto lru = work.begin();
+                for (auto k = work.begin(); k != work.end(); ++k)
+                    if (k->second.last_use < lru->second.last_use) lru = k;
+                HIP_TRY(hipDeviceSynchronize());
+                lru->second.buf.release();
+                work.erase(lru);
+            }
+            it = work.emplace(st, StreamWork()).first;
+        }
+        it->second.last_use = ++work_clock;
+        int rc = it->second.buf.ensure(need);
+        if (rc == NTT_OK) *ws = it->second.buf.ptr;
         return rc;
     }
     DevBuf io_a, io_b, io_out;  // device side of the host-pointer entry points
@@ -171,9 +189,10 @@ int do_init(int n_gpus) {
     if (e != hipSuccess || count <= 0)
         return fail(NTT_ERR_DEVICE, "no usable HIP device (this library has no CPU fallback)");
     g_visible = (n_gpus > 0 && n_gpus < count) ? n_gpus : count;
-    g_inited = true;
     Device* dev = nullptr;   // per-device set-up of the caller's current device: stream, address of the static scratch
-    return current_device(&dev);
+    const int rc = current_device(&dev);
+    if (rc == NTT_OK) g_inited = true;   // a failed set-up leaves the library uninitialised, so the next call reports the cause again
+    return rc;
 }
 
 int get_device(int id, Device** out) {
@@ -189,7 +208,8 @@ int get_device(int id, Device** out) {
         void* sp = nullptr;
         hipError_t e = hipGetSymbolAddress(&sp, HIP_SYMBOL(g_noalloc_scratch));
         if (e != hipSuccess || !sp) {
-            hipError_t e2 = hipSetDevice(prev); (void)e2;
+            hipError_t e2 = hipStreamDestroy(dev->stream); (void)e2;
+            e2 = hipSetDevice(prev); (void)e2;
             return fail(NTT_ERR_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
         }
         dev->scratch = sp;
@@ -207,22 +227,24 @@ int current_device(Device** out) {
 }
 
 // ---- optional per-kernel timing with HIP events on the launch stream ----
-// Events come from a pool that is created once and reused by every profiling session, so that a launch inside a
-// session costs two hipEventRecord calls and nothing else.  prof_begin returns the record's slot (-1: not recorded)
-// and prof_end closes exactly that slot.
+// Events come from pools that are created once and reused by every profiling session, so that a launch inside a
+// session costs two hipEventRecord calls and nothing else.  An event belongs to the device that was current when it
+// was created and can only be recorded on that device's streams, so there is one pool per device (the per-device
+// host threads of a multi-device call each draw from their own).  prof_begin returns the record's slot (-1: not
+// recorded) and prof_end closes exactly that slot.
 struct ProfRec { const char* label; hipEvent_t e0, e1; bool closed; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;       // records of the current session
-std::vector<hipEvent_t> g_prof_pool;  // every event ever created; g_prof_used of them belong to g_prof
-size_t g_prof_used = 0;
+struct ProfPool { std::vector<hipEvent_t> events; size_t used = 0; };   // every event ever created on one device
+std::map<int, ProfPool> g_prof_pools;
 constexpr size_t PROF_MAX_RECORDS = 1 << 16;  // a session stops recording beyond this many launches
 
-bool prof_event(hipEvent_t* e) {
-    if (g_prof_used < g_prof_pool.size()) { *e = g_prof_pool[g_prof_used++]; return true; }
+bool prof_event(ProfPool& pool, hipEvent_t* e) {
+    if (pool.used < pool.events.size()) { *e = pool.events[pool.used++]; return true; }
     hipEvent_t ev = nullptr;
     if (hipEventCreate(&ev) != hipSuccess) return false;
-    g_prof_pool.push_back(ev);
-    ++g_prof_used;
+    pool.events.push_back(ev);
+    ++pool.used;
     *e = ev;
     return true;
 }
@@ -233,10 +255,13 @@ int prof_begin(const char* label, hipStream_t st) {
     if (!g_prof_on) return -1;
     std::lock_guard<std::mutex> lk(g_prof_mutex);
     if (g_prof.size() >= PROF_MAX_RECORDS) return -1;
-    const size_t used_before = g_prof_used;
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess) return -1;
+    ProfPool& pool = g_prof_pools[dev_id];
+    const size_t used_before = pool.used;
     ProfRec r; r.label = label; r.e0 = nullptr; r.e1 = nullptr; r.closed = false;
-    if (!prof_event(&r.e0) || !prof_event(&r.e1) || hipEventRecord(r.e0, st) != hipSuccess) {
-        g_prof_used = used_before;  // the events go back to the pool
+    if (!prof_event(pool, &r.e0) || !prof_event(pool, &r.e1) || hipEventRecord(r.e0, st) != hipSuccess) {
+        pool.used = used_before;  // the events go back to the pool
         return -1;
     }
     g_prof.push_back(r);
@@ -514,6 +539,51 @@ template <> const FieldDConsts& consts_of<FieldD>(const Plan64& pl) { return pl.
 // factor the pointwise product leaves on the data (undone by the final scale): 2^-64 in Montgomery arithmetic, none in doubles
 uint64_t pointwise_compensation(const Plan64& pl) { return pl.fp ? 1 : pl.fc.r1; }
 
+// Known-answer probe of the double-precision field as this binary executes it, run once when a plan that uses it is
+// built: multiplies at the edges of the ranges its exactness rests on (|x| up to 2.5 p against |w| up to 0.6 p, either
+// sign), the reduction of arbitrary 64-bit words and the round trip through the memory format, computed on the device
+// and compared with 128-bit integer arithmetic here.  The field is exact only when every multiply, add and fused
+// multiply-add is executed as written; a library built with floating-point contraction left on (or any other
+// value-changing floating-point option) fails this and refuses the plan instead of returning wrong residues.
+int fieldd_probe(const Plan64& pl) {
+    constexpr int K = 16;
+    const uint64_t p = pl.fc.p;
+    const int64_t sp = (int64_t)p;
+    const int64_t xe = sp * 2 + sp / 2, we = sp / 2 + sp / 10;      // 2.5 p and 0.6 p
+    const int64_t xs[8] = {xe, -xe, xe - 1, -(xe - 1), xe, sp + sp / 4, -(sp + sp / 4), 1};
+    const int64_t ws[8] = {we, we, -we, -(we - 1), -(we - 2), sp / 2, -(sp / 2), -1};
+    const uint64_t raws[4] = {~(uint64_t)0, p, p - 1, ((uint64_t)1 << 63) + 12345};
+    const int64_t mems[4] = {xe, -xe, 0, sp / 2};
+    double hx[K] = {0}, hw[K] = {0};
+    uint64_t hraw[K] = {0}, want[K] = {0}, got[K] = {0};
+    auto canon_i = [&](__int128 v) -> uint64_t { __int128 r = v % (__int128)sp; if (r < 0) r += sp; return (uint64_t)r; };
+    for (int i = 0; i < 8; ++i) { hx[i] = (double)xs[i]; hw[i] = (double)ws[i]; want[i] = canon_i((__int128)xs[i] * ws[i]); }
+    for (int i = 0; i < 4; ++i) { hraw[8 + i] = raws[i]; want[8 + i] = raws[i] % p; }
+    for (int i = 0; i < 4; ++i) { hx[12 + i] = (double)mems[i]; want[12 + i] = canon_i(mems[i]); }
+    DevBuf buf;
+    int rc = buf.ensure(4 * K * sizeof(uint64_t));
+    if (rc != NTT_OK) return rc;
+    double* dx = (double*)buf.ptr;
+    double* dw = dx + K;
+    uint64_t* draw = (uint64_t*)(dw + K);
+    uint64_t* dout = draw + K;
+    hipError_t e = hipMemcpy(dx, hx, sizeof hx, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dw, hw, sizeof hw, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(draw, hraw, sizeof hraw, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        NTT_LAUNCH(k64_fieldd_probe, dim3(1), dim3(64), (hipStream_t) nullptr, (const double*)dx, (const double*)dw, (const uint64_t*)draw, dout, pl.fd);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost);
+    buf.release();
+    if (e != hipSuccess) return fail(NTT_ERR_DEVICE, std::string("double-precision field probe: ") + hipGetErrorString(e));
+    for (int i = 0; i < K; ++i)
+        if (got[i] != want[i])
+            return fail(NTT_ERR_DEVICE, "the double-precision field of this build is not exact (known-answer probe " + std::to_string(i) +
+                                        " failed): the library must be compiled with -ffp-contract=off and no value-changing floating-point options");
+    return NTT_OK;
+}
+
 int get_plan64(Device* dev, uint64_t p, int log_root, Plan64** out) {
     auto key = std::make_pair(p, log_root);
     auto it = dev->plans64.find(key);
@@ -596,6 +666,7 @@ int get_plan64(Device* dev, uint64_t p, int log_root, Plan64** out) {
         pl->rt.f[b] = (b >= 5 && b <= bmax) ? base + off_f[b] : nullptr;
         pl->rt.i[b] = (b >= 5 && b <= bmax) ? base + off_i[b] : nullptr;
     }
+    if (pl->fp && (rc = fieldd_probe(*pl)) != NTT_OK) { pl->tables.release(); return rc; }
     *out = pl.get();
     dev->plans64[key] = std::move(pl);
     return NTT_OK;
@@ -612,11 +683,14 @@ struct Step64 {
 
 bool is_pow2(uint64_t x) { return x && (x & (x - 1)) == 0; }
 
-std::vector<Step64> plan_steps(int log_len, size_t inner, size_t outer) {
+// joined: the axis is one of the two of a four-step matrix and its passes carry the twiddles that join them (Axis64::col_bits
+// > 0).  Only the tiled and the register passes apply those, so the contiguous-chunk kernels are not used then -- a slab one
+// column wide (inner == 1) would otherwise end in them and lose its twiddles w^(col0 * k).
+std::vector<Step64> plan_steps(int log_len, size_t inner, size_t outer, bool joined = false) {
     std::vector<Step64> steps;
     int stop = 0;
     Step64 last{Step64::LOCAL, 0, 0};
-    if (inner == 1) {
+    if (inner == 1 && !joined) {
         stop = log_len < LOCAL64_LOG ? log_len : LOCAL64_LOG;
         const bool whole_chunks = (((uint64_t)outer << log_len) & (LOCAL64_N - 1)) == 0;
         last = Step64{whole_chunks ? Step64::LOCAL : Step64::SMALL, stop, stop};
@@ -761,7 +835,7 @@ int run_step(const Plan64& pl, uint64_t* d, const Step64& s, const Axis64& ax, b
 // in-place transform along the axis
 template <class F>
 int transform64_f(const Plan64& pl, uint64_t* d, const Axis64& ax, bool inverse, hipStream_t st) {
-    const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer);
+    const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer, ax.col_bits > 0);
     const TileExtra none;
     int rc;
     if (!inverse) {
@@ -776,7 +850,7 @@ int transform64_f(const Plan64& pl, uint64_t* d, const Axis64& ax, bool inverse,
 // scaled canonical results itself: the tiled and the register-only pass can, the contiguous-chunk passes cannot.
 bool outer_pass_takes_io(const Axis64& ax) {
     if (ax.log_len <= 0) return false;
-    const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer);
+    const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer, ax.col_bits > 0);
     return !steps.empty() && (steps.front().kind == Step64::TILE || steps.front().kind == Step64::REG);
 }
 
@@ -784,7 +858,7 @@ bool outer_pass_takes_io(const Axis64& ax) {
 // only for axes for which outer_pass_takes_io() holds.
 template <class F>
 int transform64_io(const Plan64& pl, uint64_t* d, const Axis64& ax, bool inverse, const TileExtra& io, hipStream_t st) {
-    const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer);
+    const std::vector<Step64> steps = plan_steps(ax.log_len, ax.inner, ax.outer, ax.col_bits > 0);
     const TileExtra none;
     int rc;
     if (!inverse) {
@@ -1513,6 +1587,8 @@ int ntt_init(int n_gpus) {
 
 void ntt_shutdown(void) {
     NTT_API_LOCK;
+    int home = -1;
+    if (hipGetDevice(&home) != hipSuccess) home = -1;
     for (auto& kvd : g_devs) {
         Device* dev = kvd.second.get();
         hipError_t e = hipSetDevice(dev->id);
@@ -1521,7 +1597,7 @@ void ntt_shutdown(void) {
         dev->plans.clear();
         for (auto& kv : dev->plans64) kv.second->tables.release();
         dev->plans64.clear();
-        for (auto& kv : dev->work) kv.second.release();
+        for (auto& kv : dev->work) kv.second.buf.release();
         dev->work.clear();
         dev->io_a.release(); dev->io_b.release(); dev->io_out.release(); dev->pin.release();
         for (auto& s : dev->stage) {
@@ -1534,9 +1610,33 @@ void ntt_shutdown(void) {
     g_devs.clear();
     g_inited = false;
     CopyPool::shutdown();
-    g_prof.clear(); g_prof_used = 0; g_prof_on = false;
-    for (hipEvent_t ev : g_prof_pool) { hipError_t e = hipEventDestroy(ev); (void)e; }
-    g_prof_pool.clear();
+    g_prof.clear(); g_prof_on = false;
+    for (auto& kv : g_prof_pools) {
+        hipError_t e = hipSetDevice(kv.first); (void)e;
+        for (hipEvent_t ev : kv.second.events) { e = hipEventDestroy(ev); (void)e; }
+    }
+    g_prof_pools.clear();
+    if (home >= 0) { hipError_t e = hipSetDevice(home); (void)e; }
+}
+
+int ntt_release_workspace(void* stream, int all_streams) {
+    NTT_API_LOCK;
+    if (!g_inited) return NTT_OK;
+    Device* dev = nullptr;
+    int rc = current_device(&dev);
+    if (rc != NTT_OK) return rc;
+    if (all_streams) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (auto& kv : dev->work) kv.second.buf.release();
+        dev->work.clear();
+        return NTT_OK;
+    }
+    auto it = dev->work.find((hipStream_t)stream);
+    if (it == dev->work.end()) return NTT_OK;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    it->second.buf.release();
+    dev->work.erase(it);
+    return NTT_OK;
 }
 
 int ntt_device_count(void) {
@@ -2046,7 +2146,7 @@ int ntt_transform_u64(uint64_t* a, int n, int invert, uint64_t p) {
 int ntt_profile_enable(int on) {
     NTT_API_LOCK;
     g_prof.clear();
-    g_prof_used = 0;   // the pool's events are reused by the next session
+    for (auto& kv : g_prof_pools) kv.second.used = 0;   // the pools' events are reused by the next session
     g_prof_on = on != 0;
     return NTT_OK;
 }

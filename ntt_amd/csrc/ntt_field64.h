@@ -122,7 +122,7 @@ struct Field64 {
 // bounded in magnitude; the bounds below are what keeps every step exact (all quantities are integers below 2^53
 // and every quotient estimate is below 2^51).  Table twiddles are balanced (|w| <= p/2), the product of two of them
 // is below 0.6 p, and chains of such products (the pass twiddles of k64_tile) stay below 0.76 p:
-//   mulw(x, w)   needs |x w| / p < 2^51, i.e. |x| <= 2.5 p for |w| <= 0.6 p (p <= 1.5e15) and |x| <= 2.2 p for
+//   mulw(x, w)   needs |x w| / p < 2^51, i.e. |x| <= 2.5 p for |w| <= 0.6 p (p <= 1.5e15) and |x| <= 1.9 p for
 //                |w| <= 0.76 p (those only ever meet values below 1.25 p); returns |r| <= 1.25 p
 //   reduce(x)    needs |x| < 2^52; returns |r| <= p/2 + 1
 //   dif          inputs |.| <= 1.25 p -> sum reduced (<= p/2), difference (<= 2.5 p) multiplied (<= 1.25 p)

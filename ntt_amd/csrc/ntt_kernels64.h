@@ -783,6 +783,18 @@ __global__ void __launch_bounds__(256) k64_finalize(const uint64_t* data, uint64
     out[row * out_stride + i] = f.canon(f.twiddled(f.from_mem(data[row * len + i]), scale));
 }
 
+// Probe of the double-precision field (launched once per plan by the host, which compares with integer arithmetic):
+//   i < 8       out[i] = canonical(x[i] * w[i])
+//   8 <= i < 12 out[i] = canonical(raw[i] mod p)            (reduction of arbitrary 64-bit words)
+//   12 <= i <16 out[i] = canonical(from_mem(to_mem(x[i])))  (round trip through the memory format)
+__global__ void __launch_bounds__(64) k64_fieldd_probe(const double* x, const double* w, const uint64_t* raw, uint64_t* out, FieldDConsts fc) {
+    const FieldD f(fc);
+    const int i = threadIdx.x;
+    if (i < 8) out[i] = f.canon(f.mulw(x[i], w[i]));
+    else if (i < 12) out[i] = f.canon(f.from_raw(raw[i]));
+    else if (i < 16) out[i] = f.canon(f.from_mem(f.to_mem(x[i])));
+}
+
 // ---------------------------------------------------------------------------
 // k64_garner: recombination of residues modulo two or three NTT primes of like size (59 or 50 bits) into the product coefficient
 // modulo an arbitrary 64-bit p (mixed-radix / Garner form, all arithmetic in 64-bit words):

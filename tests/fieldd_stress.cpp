@@ -50,6 +50,16 @@ int main(int argc, char** argv) {
             if (!congruent(r, (i128)x * w, p) || fabs(r) > 1.25 * (double)p + 2) {
                 printf("mulw p=%lld x=%lld w=%lld r=%.0f\n", (long long)p, (long long)x, (long long)w, r); return 1;
             }
+            // chained pass twiddles (products of table twiddles, up to 0.76 p) only ever meet values up to 1.25 p
+            {
+                const int64_t w76 = (int64_t)(0.76 * (double)p);
+                int64_t x2 = rnd_sym(b125), w2 = rnd_sym(w76);
+                if ((s & 15) == 3) { x2 = (s & 16) ? b125 : -b125; w2 = (s & 32) ? w76 : -w76; }
+                const double r2 = f.mulw((double)x2, (double)w2);
+                if (!congruent(r2, (i128)x2 * w2, p) || fabs(r2) > 1.25 * (double)p + 2) {
+                    printf("mulw (chained twiddle) p=%lld x=%lld w=%lld r=%.0f\n", (long long)p, (long long)x2, (long long)w2, r2); return 1;
+                }
+            }
             // reduction of anything below 2^52
             const int64_t y = (s & 15) == 1 ? ((s & 16) ? lim52 : -lim52) : rnd_sym(lim52);
             const double q = f.reduce((double)y);

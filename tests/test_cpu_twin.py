@@ -201,13 +201,61 @@ def test_fourstep_product_with_emulated_ranks(twin, oracle):
     to_dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64).copy())
     from_dev = lambda t: t.numpy().view(np.uint64).copy()
     rng = np.random.default_rng(44)
-    for world, n in ((2, 5), (2, 3000), (4, 20000), (8, 70000), (16, 9000), (1, 5000)):
+    # (2, 2), (4, 5), (4, 8), (8, 20), (8, 32), (16, 128): slabs one column wide (transform length = world^2), whose row passes
+    # must still apply the twiddles of their column
+    for world, n in ((2, 5), (2, 3000), (4, 20000), (8, 70000), (16, 9000), (1, 5000), (2, 2), (4, 5), (4, 8), (8, 20), (8, 32), (16, 128)):
         a = rng.integers(0, 2**64, n, dtype=np.uint64); b = rng.integers(0, BIGP, n, dtype=np.uint64)
         m = 1 << (n - 1).bit_length()
         az = np.zeros(m, dtype=np.uint64); bz = np.zeros(m, dtype=np.uint64); az[:n] = a % np.uint64(BIGP); bz[:n] = b
         want = oracle.crt_ntt_multiply(az, bz, BIGP)[:2 * n - 1]
         got = emulated_fourstep_product(twin, a, b, BIGP, world, to_dev, from_dev, torch, None)
         assert np.array_equal(got, want), (world, n)
+
+
+def check_one_column_slab_rows_pass(lib, to_dev, from_dev, stream, p=BIGP):
+    """ntt64_fourstep_rows_device on slabs ONE column wide (column col0 of a 2^lr x 2^lc matrix) against the same thing
+    assembled from its parts: the plain transform of the column followed by the explicit twiddle pass w^(col0 * k)."""
+    rng = np.random.default_rng(61)
+    for lr, lc, col0 in ((3, 3, 5), (5, 2, 3), (8, 4, 9), (13, 1, 1), (14, 3, 7), (1, 1, 1), (6, 6, 0)):
+        lt = lr + lc
+        x = rng.integers(0, p, 1 << lr, dtype=np.uint64)
+        got = to_dev(x)
+        lib.check(lib.lib.ntt64_fourstep_rows_device(got.data_ptr(), p, lt, lr, 1, col0, 0, stream))
+        want = to_dev(x)
+        lib.check(lib.lib.ntt64_transform_device(want.data_ptr(), p, lt, lr, 1, 1, 0, stream))
+        lib.check(lib.lib.ntt64_twiddle_device(want.data_ptr(), p, lt, 1 << lr, 1, 0, col0, lr, 1, 0, stream))
+        assert np.array_equal(from_dev(got) % np.uint64(p), from_dev(want) % np.uint64(p)), (lr, lc, col0)
+        # and back: the inverse pass undoes it up to the factor 2^lr
+        lib.check(lib.lib.ntt64_fourstep_rows_device(got.data_ptr(), p, lt, lr, 1, col0, 1, stream))
+        back = from_dev(got).astype(object) % p * pow(1 << lr, p - 2, p) % p
+        assert np.array_equal(back.astype(np.uint64), x), (lr, lc, col0)
+
+
+def test_rows_pass_of_a_one_column_slab_keeps_its_twiddles(twin):
+    import torch
+    check_one_column_slab_rows_pass(twin, lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64).copy()),
+                                    lambda t: t.numpy().view(np.uint64).copy(), None)
+
+
+def test_library_workspaces_are_capped_and_can_be_released(twin):
+    """NULL-workspace device calls keep one library-owned workspace per stream, at most eight of them; more streams evict
+    the least recently used, and ntt_release_workspace frees them on request -- results stay right throughout."""
+    import torch
+    rng = np.random.default_rng(8)
+    p, n = 998244353, 16384
+    a = rng.integers(0, p, n, dtype=np.uint32); b = rng.integers(0, p, n, dtype=np.uint32)
+    from oracle_binding import Oracle
+    want = Oracle().ntt_multiply(a, b, p)
+    ta, tb = torch.from_numpy(a.view(np.int32).copy()), torch.from_numpy(b.view(np.int32).copy())
+    for fake_stream in list(range(1, 12)) + [3, 1]:       # the twin ignores the handle's meaning; the map is keyed by it
+        out = torch.zeros(2 * n - 1, dtype=torch.int32)
+        twin.check(twin.lib.ntt_poly_multiply_batched_device(ta.data_ptr(), tb.data_ptr(), out.data_ptr(), n, p, 1, n, n, 2 * n - 1, None, 0, fake_stream))
+        assert np.array_equal(out.numpy().view(np.uint32).astype(np.uint64), want)
+    assert twin.lib.ntt_release_workspace(3, 0) == 0 and twin.lib.ntt_release_workspace(777, 0) == 0
+    assert twin.lib.ntt_release_workspace(None, 1) == 0
+    out = torch.zeros(2 * n - 1, dtype=torch.int32)
+    twin.check(twin.lib.ntt_poly_multiply_batched_device(ta.data_ptr(), tb.data_ptr(), out.data_ptr(), n, p, 1, n, n, 2 * n - 1, None, 0, 5))
+    assert np.array_equal(out.numpy().view(np.uint32).astype(np.uint64), want)
 
 
 def test_route_selection_beyond_the_reference_range(twin):

@@ -83,7 +83,8 @@ def test_explicit_fourstep_single_gpu(gpu_lib, oracle, n):
     assert np.array_equal(poly_multiply_fourstep(gpu_lib, a, b, BIGP, torch.device("cuda", 0)), want)
 
 
-@pytest.mark.parametrize("world,n", [(2, 5), (2, 3000), (4, 20000), (8, 70000), (16, 9000), (8, 131072), (2, 100000)])
+@pytest.mark.parametrize("world,n", [(2, 5), (2, 3000), (4, 20000), (8, 70000), (16, 9000), (8, 131072), (2, 100000),
+                                     (2, 2), (4, 8), (8, 32), (16, 128)])   # the last four: slabs one column wide
 def test_fourstep_product_with_emulated_ranks(gpu_lib, oracle, world, n):
     """The multi-rank four-step product with every rank emulated on this one GPU (exchanges as tensor copies): the pass over
     the parts and the transforms on sub-ranges of a part run as GPU kernels here, not only on real multi-GPU nodes."""
@@ -170,3 +171,12 @@ def test_transform_along_a_strided_axis_tiled_and_register_passes(gpu_lib, oracl
     for log_len, inner, outer in [(10, 6, 2), (9, 8, 1), (11, 16, 1), (5, 3, 3), (13, 1, 2), (14, 1, 1), (4, 40, 2),
                                   (18, 1, 1), (9, 512, 1), (12, 24, 2)]:
         check_middle_axis_transform(gpu_lib, oracle, to_dev, from_dev, st, 23, log_len, inner, outer)
+
+
+def test_rows_pass_of_a_one_column_slab_keeps_its_twiddles(gpu_lib):
+    """Slabs one column wide (cols_local == 1, col0 != 0): the row passes must be ones that carry the inter-axis twiddles."""
+    import torch
+    from test_cpu_twin import check_one_column_slab_rows_pass
+    to_dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64).copy()).cuda()
+    from_dev = lambda t: t.cpu().numpy().view(np.uint64).copy()
+    check_one_column_slab_rows_pass(gpu_lib, to_dev, from_dev, torch.cuda.current_stream().cuda_stream)
