@@ -1,4 +1,4 @@
-"""Large-modulus products with the CRT work spread over ranks (one process per GPU).
+"""Large-modulus products with the CRT work spread over ranks (one process per GPU), device-resident.
 
 What the reference's MPI variant does (main_mpi_CRT.cc:464-529): rank r runs the residue products of primes
 i = r, r + size, ... (:470); every prime's residue vector is broadcast to all ranks (:498-501); every rank merges a contiguous
@@ -6,90 +6,137 @@ coefficient slice (:507-522); the zero-padded slices are summed onto rank 0 (`MP
 leaves ranks 4.. idle and moves every residue to every rank.
 
 Here the unit of work is (prime, row) of a batch -- 4 * batch independent residue products -- dealt to the ranks in
-contiguous runs, so that eight ranks are all busy from two rows on.  The exchange is ONE all-to-all: the (row, coefficient)
-space is cut into `world` equal slices, and each rank sends, of every residue row it computed, only the part that lies in the
-destination's slice (a 1/world share of the data per link, instead of a broadcast of everything).  Each rank merges its
-slice of all four residues (`ntt_crt_merge_device`), and the slices are gathered -- to rank 0, like the reference, or to all
-ranks on request.  No zero-padded all-reduce.  All arithmetic runs in the library's kernels through its C ABI; torch provides
-device memory and the collectives (RCCL on GPUs, gloo on CPU in the tests); on a GPU everything is ordered on the current
-stream, without host synchronisation between the steps.
-"""
+contiguous runs, so that eight ranks are all busy from two rows on.  The exchange is ONE all-to-all: the coefficient axis
+is cut into `world` equal slices of Lw = L / world coefficients, and each rank sends, of every residue row it computed,
+only the slice the destination owns (a 1/world share of the data per link, instead of a broadcast of everything).  The
+send buffer is the rank's residue rows viewed as [units][world][Lw] with the first two axes swapped -- one strided copy,
+no per-segment packing -- and because the ranks hold contiguous runs of units in rank order, what arrives is already the
+four residue planes [4][batch][Lw] of the receiver's slice: nothing is unpacked.  Each rank merges its slice
+(`ntt_crt_merge_device`) and keeps it; gathering the slices is optional.  No zero-padded all-reduce, no host memory
+between the residue products and the merge.
+
+All arithmetic runs in the library's kernels through its C ABI; torch provides device memory and the collectives (RCCL on
+GPUs, gloo on CPU in the tests).  On a GPU with RCCL everything is ordered on torch's current stream and the host never
+waits between the steps; any other backend on a GPU moves device memory from the host side, so the exchange is then
+bracketed by device synchronisation."""
 import numpy as np
 
 from .sharding import crt_unit_range
 
 
-def crt_multiply_distributed(lib, a, b, p, dist, device, stream=None, all_ranks=True):
-    """a, b: uint64 arrays of shape [n] or [batch, n], identical on every rank (the reference broadcasts them,
-    main_mpi_CRT.cc:569-572).  lib: NttLibrary; dist: torch.distributed (initialised); device: torch device of this rank.
-    Returns the products, shape [batch, 2n-1] (or [2n-1]), on every rank (all_ranks=True) or on rank 0 only (None elsewhere)."""
+def collectives_follow_the_stream(dist, device):
+    """True when this process group's transfers are enqueued on the device stream (RCCL), or there is no device stream
+    to race with (CPU tensors)."""
+    return device.type != "cuda" or dist is None or dist.get_backend() == "nccl"
+
+
+class CrtDistributed:
+    """Context of one rank for batches of `batch` products of n coefficients modulo p, the same operands on every rank
+    (the reference broadcasts them, main_mpi_CRT.cc:569-572).  Buffers are allocated once, here.
+
+    multiply(ta, tb) -> this rank's slice of the products: int64 tensor [batch][Lw], coefficients
+    [rank * Lw, (rank + 1) * Lw) of every row (positions from 2n-1 on are padding and hold zeros).
+    gather(slice) -> the full products [batch][2n-1] on every rank or on rank 0."""
+
+    def __init__(self, lib, p, n, batch, device, dist=None):
+        import torch
+        self.torch, self.lib, self.p, self.n, self.batch, self.device = torch, lib, int(p), int(n), int(batch), device
+        self.dist = dist if dist is not None and dist.is_initialized() and dist.get_world_size() > 1 else None
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.L = 1 << max(1, (2 * self.n - 2).bit_length())
+        self.Lw = -(-self.L // self.world)                      # coefficients per slice
+        self.Lp = self.Lw * self.world                          # row length of the residue buffer (>= L)
+        self.u_lo, self.u_hi = crt_unit_range(self.batch, self.rank, self.world)
+        self.units = [crt_unit_range(self.batch, r, self.world) for r in range(self.world)]
+        nu = self.u_hi - self.u_lo
+        # residue rows of this rank's units; the products write 2n-1 values per row, the rest stays zero
+        self.local = torch.zeros((max(nu, 1), self.Lp), dtype=torch.int32, device=device)
+        self.send = torch.empty((self.world, nu, self.Lw), dtype=torch.int32, device=device)
+        self.recv = torch.empty((4 * self.batch, self.Lw), dtype=torch.int32, device=device)
+        self.out = torch.empty((self.batch, self.Lw), dtype=torch.int64, device=device)
+        self.equal_split = all(hi - lo == nu for lo, hi in self.units)
+        self.in_splits = [nu * self.Lw] * self.world
+        self.out_splits = [(hi - lo) * self.Lw for lo, hi in self.units]
+        self.stream_ordered = collectives_follow_the_stream(self.dist, device)
+        ws_rows = min(self.batch, max(nu, 1))
+        self.ws_bytes = lib.lib.ntt_workspace_bytes(self.n, int(lib.lib.ntt_crt_prime(0)), ws_rows)
+        self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=device)
+
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
+
+    def _host_wait(self):
+        if not self.stream_ordered:
+            self.torch.cuda.synchronize(self.device)
+
+    def multiply(self, ta, tb):
+        """ta, tb: int64 device tensors [batch][n] (any 64-bit words; they are reduced modulo each prime on the fly)."""
+        L, lib, n, st = self.lib.lib, self.lib, self.n, self._stream()
+        assert ta.shape == (self.batch, n) and tb.shape == (self.batch, n) and ta.is_contiguous() and tb.is_contiguous()
+        # 1. residue products of this rank's (prime, row) units; unit u = prime * batch + row.  One library call per
+        #    prime: its rows inside this rank's run are contiguous (at most four calls)
+        u = self.u_lo
+        while u < self.u_hi:
+            prime, row = divmod(u, self.batch)
+            rows = min(self.u_hi, (prime + 1) * self.batch) - u
+            lib.check(L.ntt_crt_residue_product_device(ta.data_ptr() + 8 * row * n, tb.data_ptr() + 8 * row * n,
+                                                       self.local[u - self.u_lo].data_ptr(), n, prime, rows, n, n, self.Lp,
+                                                       self.ws.data_ptr(), self.ws_bytes, st))
+            u += rows
+        # 2. one all-to-all of coefficient slices
+        nu = self.u_hi - self.u_lo
+        if self.world == 1:
+            recv = self.local[:nu]
+        else:
+            if nu:
+                self.send.copy_(self.local[:nu].view(nu, self.world, self.Lw).transpose(0, 1))
+            self._host_wait()
+            if self.equal_split:
+                self.dist.all_to_all_single(self.recv.view(-1), self.send.view(-1))
+            else:
+                self.dist.all_to_all_single(self.recv.view(-1), self.send.view(-1), output_split_sizes=self.out_splits,
+                                            input_split_sizes=self.in_splits)
+            self._host_wait()
+            recv = self.recv
+        # 3. merge this rank's slice of the four residue planes [4][batch][Lw]
+        count = self.batch * self.Lw
+        lib.check(L.ntt_crt_merge_device(recv.data_ptr(), count, self.out.data_ptr(), count, self.p, st))
+        return self.out
+
+    def gather(self, out, all_ranks=True):
+        """Slices of all ranks -> full products, int64 tensor [batch][2n-1] (None on ranks other than 0 unless all_ranks)."""
+        t = self.torch
+        if self.world == 1:
+            return out[:, :2 * self.n - 1]
+        self._host_wait()
+        if all_ranks:
+            parts = [t.empty_like(out) for _ in range(self.world)]
+            self.dist.all_gather(parts, out)
+        else:
+            parts = [t.empty_like(out) for _ in range(self.world)] if self.rank == 0 else None
+            self.dist.gather(out, parts, dst=0)
+            if self.rank != 0:
+                return None
+        self._host_wait()
+        return t.stack(parts, dim=1).reshape(self.batch, self.Lp)[:, :2 * self.n - 1]
+
+
+def crt_multiply_distributed(lib, a, b, p, dist, device, all_ranks=True):
+    """Host-array face of CrtDistributed (tests, small calls): a, b uint64 arrays of shape [n] or [batch, n], identical on
+    every rank.  Returns the products, shape [batch, 2n-1] (or [2n-1]), on every rank (all_ranks=True) or on rank 0 only
+    (None elsewhere)."""
     import torch
     a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)
     single = a.ndim == 1
     if single:
         a, b = a[None, :], b[None, :]
     batch, n = a.shape
-    L = 1 << max(1, (2 * n - 2).bit_length())
-    world, rank = dist.get_world_size(), dist.get_rank()
-    st = stream if stream is not None else (torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else None)
+    ctx = CrtDistributed(lib, p, n, batch, device, dist)
     ta = torch.from_numpy(a.view(np.int64)).to(device)
     tb = torch.from_numpy(b.view(np.int64)).to(device)
-
-    # 1. residue products of this rank's (prime, row) units; unit u = prime * batch + row
-    u_lo, u_hi = crt_unit_range(batch, rank, world)
-    local = torch.zeros((max(u_hi - u_lo, 1), L), dtype=torch.int32, device=device)
-    u = u_lo
-    while u < u_hi:                       # one library call per prime: its rows in this rank's run are contiguous
-        prime, row = divmod(u, batch)
-        rows = min(u_hi, (prime + 1) * batch) - u
-        lib.check(lib.lib.ntt_crt_residue_product_device(ta.data_ptr() + 8 * row * n, tb.data_ptr() + 8 * row * n,
-                                                         local[u - u_lo].data_ptr(), n, prime, rows, n, n, L, None, 0, st))
-        u += rows
-
-    # 2. one all-to-all: slice s of the flattened (row, coefficient) space [batch * L] belongs to rank s
-    total = batch * L
-    per = -(-total // world)
-    def slice_of(r):
-        return min(r * per, total), min((r + 1) * per, total)
-    def segments(units, sl):
-        """For a run of units and a slice: (unit, start, stop) of the part of each unit's row that lies in the slice."""
-        lo, hi = sl
-        out = []
-        for uu in range(*units):
-            row = uu % batch
-            s, e = max(lo, row * L), min(hi, (row + 1) * L)
-            if s < e:
-                out.append((uu, s, e))
-        return out
-    send_parts, send_counts = [], []
-    for dst in range(world):
-        segs = segments((u_lo, u_hi), slice_of(dst))
-        send_counts.append(sum(e - s for _, s, e in segs))
-        send_parts += [local[uu - u_lo, s - (uu % batch) * L:e - (uu % batch) * L] for uu, s, e in segs]
-    send = torch.cat(send_parts) if send_parts else torch.zeros(0, dtype=torch.int32, device=device)
-    my_lo, my_hi = slice_of(rank)
-    recv_segs = [segments(crt_unit_range(batch, src, world), (my_lo, my_hi)) for src in range(world)]
-    recv_counts = [sum(e - s for _, s, e in segs) for segs in recv_segs]
-    recv = torch.empty(sum(recv_counts), dtype=torch.int32, device=device)
-    dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts)
-    res = torch.zeros((4, per), dtype=torch.int32, device=device)      # this rank's slice of the four residue planes
-    off = 0
-    for segs in recv_segs:
-        for uu, s, e in segs:
-            res[uu // batch, s - my_lo:e - my_lo] = recv[off:off + e - s]
-            off += e - s
-
-    # 3. merge the slice, 4. gather the slices
-    out = torch.zeros(per, dtype=torch.int64, device=device)
-    if my_hi > my_lo:
-        lib.check(lib.lib.ntt_crt_merge_device(res.data_ptr(), per, out.data_ptr(), my_hi - my_lo, int(p), st))
-    if all_ranks:
-        parts = [torch.empty_like(out) for _ in range(world)]
-        dist.all_gather(parts, out)
-    else:
-        parts = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
-        dist.gather(out, parts, dst=0)
-        if rank != 0:
-            return None
-    full = torch.cat(parts)[:total].cpu().numpy().view(np.uint64).reshape(batch, L)[:, :2 * n - 1].copy()
+    full = ctx.gather(ctx.multiply(ta, tb), all_ranks=all_ranks)
+    if full is None:
+        return None
+    full = full.cpu().numpy().view(np.uint64).copy()
     return full[0] if single else full

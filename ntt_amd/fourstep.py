@@ -74,6 +74,11 @@ class FourStep:
         while self.Rl % self.chunks:
             self.chunks -= 1
         self.stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else None
+        # RCCL enqueues its transfers on the device stream, which is what orders them against the library's kernels; any
+        # other backend on a GPU (gloo) moves device memory from the host side, so the exchanges are then bracketed by
+        # device synchronisation instead
+        from .distributed import collectives_follow_the_stream
+        self.stream_ordered = collectives_follow_the_stream(dist if self.world > 1 else None, device)
 
     # -- data placement ---------------------------------------------------------------
     def column_slab(self, full):
@@ -85,12 +90,30 @@ class FourStep:
         slab = v.reshape(self.R, self.C)[:, self.rank * self.Cl:(self.rank + 1) * self.Cl]
         return t.from_numpy(np.ascontiguousarray(slab).view(np.int64)).to(self.device)
 
+    def column_slab_device(self, full):
+        """The same from a coefficient vector that is already on the device (int64 tensor of n words): only the rows
+        that hold coefficients are filled; the rest of the slab is never read by multiply_slabs."""
+        t = self.torch
+        slab = t.empty((self.R, self.Cl), dtype=t.int64, device=self.device)
+        lo, hi = self.rank * self.Cl, (self.rank + 1) * self.Cl
+        whole = self.n // self.C                                  # complete matrix rows of coefficients
+        if whole:
+            slab[:whole].copy_(full[: whole * self.C].view(whole, self.C)[:, lo:hi])
+        rest = self.n - whole * self.C
+        if rest and whole < self.R:
+            slab[whole].zero_()
+            if rest > lo:
+                slab[whole, : min(rest, hi) - lo].copy_(full[whole * self.C + lo: whole * self.C + min(rest, hi)])
+        return slab
+
     def _exchange(self, send, recv, rows):
         """All-to-all of rows [rows[0], rows[1]) of every rank's chunk: send / recv are [G][Rl][Cl] arrays, chunk g of
         `send` goes to rank g and chunk g of `recv` comes from it.  Written as one batch of point-to-point transfers
         (what an all-to-all is on RCCL: a group of sends and receives over all xGMI links at once), so that the pieces
         need no packing and the same code runs on gloo.  Returns the pending transfers."""
         lo, hi = rows
+        if not self.stream_ordered:
+            self.torch.cuda.synchronize(self.device)          # the kernels that produced `send` have finished
         recv[self.rank, lo:hi].copy_(send[self.rank, lo:hi])
         ops = []
         for g in range(self.world):
@@ -98,6 +121,13 @@ class FourStep:
                 ops.append(self.dist.P2POp(self.dist.irecv, recv[g, lo:hi], g))
                 ops.append(self.dist.P2POp(self.dist.isend, send[g, lo:hi], g))
         return self.dist.batch_isend_irecv(ops) if ops else []
+
+    def _wait(self, works):
+        """Completion of pending transfers: ordered on the stream with RCCL, waited for by the host otherwise."""
+        for w in works:
+            w.wait()
+        if works and not self.stream_ordered:
+            self.torch.cuda.synchronize(self.device)
 
     def _row_pieces(self):
         per = self.Rl // self.chunks
@@ -118,8 +148,7 @@ class FourStep:
         pieces = self._row_pieces()
         works = [self._exchange(send, recv, rows) for rows in pieces]          # all issued behind the row pass
         for pending, (lo, hi) in zip(works, pieces):
-            for w in pending:
-                w.wait()                                                        # orders the stream, not the host, on GPUs
+            self._wait(pending)                                                 # orders the stream, not the host, with RCCL
             lib.check(L.ntt64_fourstep_cols_device(recv.data_ptr() + 8 * lo * self.Cl, p, lt, self.log_cols, self.log_parts,
                                                    self.Rl * self.Cl, hi - lo, 0, self.stream))
         return recv
@@ -139,8 +168,7 @@ class FourStep:
                                                        self.Rl * self.Cl, hi - lo, 1, self.stream))
                 works.append(self._exchange(z, back, (lo, hi)))                # travels while the next piece is transformed
             for pending in works:
-                for w in pending:
-                    w.wait()
+                self._wait(pending)
             x = back.view(self.R, self.Cl)
         lib.check(L.ntt64_fourstep_rows_device(x.data_ptr(), p, lt, self.log_rows, self.Cl, self.rank * self.Cl, 1, self.stream))
         out = self.torch.empty_like(x)
@@ -174,15 +202,13 @@ class FourStep:
             back = t.empty_like(za)
             returning = []
             for k, (lo, hi) in enumerate(pieces):
-                for w in pending[0][k] + pending[1][k]:
-                    w.wait()                                        # orders the stream, not the host, on GPUs
+                self._wait(pending[0][k] + pending[1][k])            # orders the stream, not the host, with RCCL
                 off = 8 * lo * self.Cl
                 lib.check(L.ntt64_fourstep_cols_product_device(za.data_ptr() + off, zb.data_ptr() + off, p, lt, self.log_cols,
                                                                self.log_parts, self.Rl * self.Cl, hi - lo, self.stream))
                 returning.append(self._exchange(za, back, (lo, hi)))   # travels while the next piece is worked on
             for works in returning:
-                for w in works:
-                    w.wait()
+                self._wait(works)
             x = back.view(self.R, self.Cl)
         out = t.empty_like(x)
         lib.check(L.ntt64_fourstep_rows_store_device(x.data_ptr(), out.data_ptr(), p, lt, self.log_rows, self.Cl, self.rank * self.Cl,
@@ -200,9 +226,16 @@ class FourStep:
     def gather(self, slab, all_ranks=False):
         """The ranks' column slabs -> the full product (numpy uint64, 2n-1 values) on rank 0 (None elsewhere), or on every
         rank with all_ranks=True.  A product this long normally stays sharded; this is for checking."""
+        full = self.gather_device(slab, all_ranks)
+        return None if full is None else full.cpu().numpy().view(np.uint64).copy()
+
+    def gather_device(self, slab, all_ranks=False):
+        """The same, staying on the device: int64 tensor of 2n-1 words."""
         t = self.torch
         slab = slab.contiguous()
         if self.world > 1:
+            if not self.stream_ordered:
+                t.cuda.synchronize(self.device)
             if all_ranks:
                 parts = [t.empty_like(slab) for _ in range(self.world)]
                 self.dist.all_gather(parts, slab)
@@ -211,10 +244,12 @@ class FourStep:
                 self.dist.gather(slab, parts, dst=0)
                 if self.rank != 0:
                     return None
+            if not self.stream_ordered:
+                t.cuda.synchronize(self.device)
             full = t.cat(parts, dim=1)
         else:
             full = slab
-        return full.cpu().numpy().view(np.uint64).reshape(-1)[: 2 * self.n - 1].copy()
+        return full.reshape(-1)[: 2 * self.n - 1]
 
 
 def poly_multiply_fourstep(lib, a, b, p, device, dist=None, chunks=4):

@@ -71,6 +71,18 @@ for bt, nn in ((1, 4), (2, 1), (5, 8), (world, 512), (2 * world + 1, 64)):   # b
         ok3 = ok3 and all(np.array_equal(got5[r], orc.schoolbook_u64(A5[r], B5[r], P)) for r in range(bt))
     else:
         ok3 = ok3 and got5 is None
+# the device-resident form: tensors in, this rank's coefficient slice out, buffers reused by a second call
+from ntt_amd.distributed import CrtDistributed
+ctx = CrtDistributed(lib, P, 512, 3, torch.device("cpu"), dist)
+for seed in (1, 2):
+    r7 = np.random.default_rng(seed)
+    A7 = r7.integers(0, P, (3, 512), dtype=np.uint64); B7 = r7.integers(0, P, (3, 512), dtype=np.uint64)
+    sl = ctx.multiply(torch.from_numpy(A7.view(np.int64)), torch.from_numpy(B7.view(np.int64)))
+    want7 = np.zeros((3, ctx.Lp), dtype=np.uint64)
+    for r in range(3):
+        want7[r, :1023] = orc.crt_ntt_multiply(A7[r], B7[r], P)
+    ok3 = ok3 and sl.shape == (3, ctx.Lw) and np.array_equal(sl.numpy().view(np.uint64), want7[:, rank * ctx.Lw:(rank + 1) * ctx.Lw])
+    ok3 = ok3 and np.array_equal(ctx.gather(sl).numpy().view(np.uint64), want7[:, :1023])
 busy = crt_unit_range(2, rank, world)
 ok3 = ok3 and (busy[1] > busy[0] or world > 8)          # two rows keep up to eight ranks busy
 flag = torch.tensor([1 if ok3 else 0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN); ok3 = bool(flag.item())
@@ -87,7 +99,8 @@ for n4 in (4096, 1000, 16384, 70000):
 from ntt_amd.fourstep import FourStep
 fs = FourStep(lib, P, 5000, torch.device("cpu"), dist, chunks=2)
 A6 = rng.integers(0, P, 5000, dtype=np.uint64); B6 = rng.integers(0, P, 5000, dtype=np.uint64)
-got6 = fs.gather(fs.multiply_slabs(fs.column_slab(A6), fs.column_slab(B6)))
+ok4 = ok4 and all(np.array_equal(fs.column_slab_device(torch.from_numpy(v.view(np.int64)))[:2].numpy(), fs.column_slab(v)[:2].numpy()) for v in (A6, B6))
+got6 = fs.gather(fs.multiply_slabs(fs.column_slab_device(torch.from_numpy(A6.view(np.int64))), fs.column_slab(B6)))
 ok4 = ok4 and (np.array_equal(got6, orc.schoolbook_u64(A6, B6, P)) if rank == 0 else got6 is None)
 flag = torch.tensor([1 if ok4 else 0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN); ok4 = bool(flag.item())   # every rank's verdict
 slow = max_over_ranks(float(rank + 1), dist)
