@@ -110,67 +110,90 @@ def valu_roofline(kernel, batch, avg_ms):
         return None
 
 
-def other_configurations(torch, lib, stream):
-    """The remaining single-GPU configurations of the baseline, timed on the idle GPU after the headline (same entry
-    points, operands resident in HBM, steady state after an untimed ramp).  Reported beside the headline, never as
-    `value`; their bit-exactness is the business of the GPU test suite, here each result is only spot-checked by the
-    evaluation identity c(1) = a(1) b(1) mod p on one product."""
-    L = lib.lib
-    big = 1337006139375617
+def other_configurations(torch, dist, lib, clock, sizes):
+    """The remaining configurations of the baseline, timed after the headline by the same rank processes (operands
+    generated on the devices, steady state after an untimed ramp) and reported beside it, never as `value`.
+      one rank:      config 3 (65536 x n = 4096), config 4 by both routes, config 5 directly and in its explicit four-step form
+      several ranks: config 3 and config 4 sharded by batch (weak scaling), config 4 by the reference's MPI route -- (prime, row)
+                     units over the ranks, one all-to-all, slice merge -- and config 5 with the matrix sharded over the ranks
+                     (strong scaling), the way one `mpiexec` run of the reference times all its variants (main_mpi_CRT.cc:556-597).
+    Every entry carries a roofline block and a verification verdict reduced over the ranks.  The checks are test
+    infrastructure (tests/evalcheck.py: evaluation identities in torch integer arithmetic); bit-exactness against the oracle
+    is the business of the GPU test suite."""
+    from ntt_amd import workloads as W
+    import evalcheck
+    world, rank = clock.world, (dist.get_rank() if clock.dist is not None else 0)
+    g = torch.Generator(device="cpu"); g.manual_seed(0xE7A1)        # the same evaluation points on every rank
+
+    def point(p):
+        return int(torch.randint(2, min(p, 1 << 62) - 1, (1,), generator=g).item())
+
+    def rows_identity(a, b, c, n, p, sample=256):
+        """A_r(x) B_r(x) = C_r(x) mod p on a sample of rows (all of them when there are few) at one random point."""
+        x = point(p)
+        rows = a.shape[0]
+        pick = torch.arange(0, rows, max(1, rows // sample), device=a.device)
+        def vals(t):
+            t = t[pick].to(torch.int64)
+            if t.dtype != a.dtype or a.dtype == torch.int32:
+                t = t & 0xFFFFFFFF
+            return evalcheck.evaluate_rows(t, x, p)
+        va, vb, vc = vals(a), vals(b), vals(c)
+        return all(x_ * y_ % p == z_ for x_, y_, z_ in zip(va, vb, vc))
+
+    def crt_slice_equals_direct(ctx, a, b, out, n, p):
+        """This rank's coefficient slice from the split CRT route against the same slice of the products computed here by the
+        default route (the two routes are bit-identical wherever both apply)."""
+        ref = torch.zeros((ctx.batch, ctx.Lp), dtype=torch.int64, device=a.device)
+        st = torch.cuda.current_stream(a.device).cuda_stream if a.device.type == "cuda" else None
+        lib.check(lib.lib.ntt_poly_multiply_batched_device_u64(a.data_ptr(), b.data_ptr(), ref.data_ptr(), n, p, ctx.batch, n, n, ctx.Lp, None, 0, st))
+        return bool(torch.equal(out, ref[:, ctx.rank * ctx.Lw:(ctx.rank + 1) * ctx.Lw]))
+
+    def long_identity(a, b, c, p):
+        ok = True
+        for _ in range(2):
+            x = point(p)
+            ok = ok and evalcheck.evaluate(a, x, p) * evalcheck.evaluate(b, x, p) % p == evalcheck.evaluate(c, x, p)
+        return ok
+
+    def slabs_identity(fs, a, b, c, p):
+        """A(x) B(x) = C(x) at two random points; every rank evaluates its column slabs, the shares are summed over the ranks."""
+        ok = True
+        rows_in = min(fs.R, -(-fs.n // fs.C))
+        for _ in range(2):
+            x = point(p)
+            share = [evalcheck.evaluate_slab(t, fs.rank * fs.Cl, fs.C, x, p, rows) for t, rows in ((a, rows_in), (b, rows_in), (c, fs.R))]
+            if clock.dist is not None:
+                parts = [None] * world
+                dist.all_gather_object(parts, share)
+                share = [sum(q[i] for q in parts) % p for i in range(3)]
+            ok = ok and share[0] * share[1] % p == share[2]
+        return ok
+
+    c3, c4, c5 = sizes["c3"], sizes["c4"], sizes["c5"]
+    if world == 1:
+        jobs = [lambda: W.small_batched(torch, lib, clock, c3["n"], 998244353, c3["batch"], 10, rows_identity),
+                lambda: W.large_modulus(torch, lib, clock, c4["n"], W.BIG_P, c4["batch"], 20, "auto", rows_identity),
+                lambda: W.large_modulus(torch, lib, clock, c4["n"], W.BIG_P, c4["batch"], 20, "reference", rows_identity),
+                lambda: W.long_product_direct(torch, lib, clock, c5["log_n"], W.BIG_P, 3, long_identity),
+                lambda: W.long_product(torch, lib, clock, c5["log_n"], W.BIG_P, 3, 4, slabs_identity)]
+    else:
+        jobs = [lambda: W.small_batched(torch, lib, clock, c3["n"], 998244353, c3["batch"], 10, rows_identity),
+                lambda: W.large_modulus(torch, lib, clock, c4["n"], W.BIG_P, c4["batch"], 20, "auto", rows_identity),
+                lambda: W.large_modulus_crt_split(torch, lib, clock, c4["n"], W.BIG_P, c4["batch"], 20, crt_slice_equals_direct),
+                lambda: W.long_product(torch, lib, clock, c5["log_n"], W.BIG_P, 3, 4, slabs_identity)]
     out = []
-
-    def timed(fn, reps, ramp_s=0.15):
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < ramp_s:
-            fn()
-            torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps
-
-    def at_one(t, p):        # sum of a non-negative int64 vector modulo p without overflow
-        t = t.reshape(-1)
-        while t.numel() > 1:
-            pad = (-t.numel()) % 1024
-            if pad:
-                t = torch.cat([t, torch.zeros(pad, dtype=t.dtype, device=t.device)])
-            t = t.view(-1, 1024).sum(dim=1) % p
-        return int(t.item())
-
-    def run(name, n, p, batch, wide, reps, policy="auto"):
-        gen = torch.Generator(device="cuda"); gen.manual_seed(n + batch)
-        a = torch.randint(0, p, (batch, n), generator=gen, device="cuda", dtype=torch.int64)
-        b = torch.randint(0, p, (batch, n), generator=gen, device="cuda", dtype=torch.int64)
-        if not wide:
-            a, b = a.to(torch.int32), b.to(torch.int32)
-        c = torch.zeros((batch, 2 * n - 1), dtype=a.dtype, device="cuda")
-        lib.set_route_policy(policy)
-        try:
-            fn_c = L.ntt_poly_multiply_batched_device_u64 if wide else L.ntt_poly_multiply_batched_device
-            def fn():
-                lib.check(fn_c(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, p, batch, n, n, 2 * n - 1, None, 0, stream))
-            dt = timed(fn, reps)
-            kernels = lib.describe_plan(n, p)
-        finally:
-            lib.set_route_policy("auto")
-        r = batch - 1
-        ok = at_one(a[r].to(torch.int64), p) * at_one(b[r].to(torch.int64), p) % p == at_one(c[r].to(torch.int64), p)
-        out.append({"config": name, "n": n, "p": p, "batch": batch, "ms_per_call": dt * 1e3, "poly_mults_per_s": batch / dt,
-                    "kernels": kernels, "spot_check": bool(ok)})
-
-    jobs = [("65536 x n=4096 (batched small products)", 4096, 998244353, 65536, False, 10, "auto"),
-            ("large modulus n=2^17, 64 products (direct 64-bit field, default route)", 131072, big, 64, True, 20, "auto"),
-            ("large modulus n=2^17, 64 products (four-prime CRT, the reference's route)", 131072, big, 64, True, 20, "reference"),
-            ("one product of n=2^28 coefficients, large modulus", 1 << 28, big, 1, True, 3, "auto")]
     for job in jobs:
-        try:
-            run(*job)
-        except Exception as e:   # a failure here must not take the headline line with it
-            out.append({"config": job[0], "error": f"{type(e).__name__}: {e}"})
-        torch.cuda.empty_cache()
-    return out
+        if world == 1:
+            try:
+                out.append(job())
+            except Exception as e:   # a failure here must not take the headline line with it
+                out.append({"error": f"{type(e).__name__}: {e}"})
+        else:
+            out.append(job())        # across ranks a failure must end the run: a rank that skipped a workload would leave the others waiting
+        if clock.device.type == "cuda":
+            torch.cuda.empty_cache()
+    return out if rank == 0 else None
 
 
 def free_port():
@@ -192,8 +215,32 @@ def launch_ranks(args, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    # rank 0's output is read by a thread while every rank is watched: when one rank ends badly the others (blocked in a
+    # collective that can no longer complete) are ended too, by their own process ids
+    import threading
+    captured = []
+    reader = threading.Thread(target=lambda: captured.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, q in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = q.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, q in enumerate(procs):
+                if codes[i] is None:
+                    q.terminate()
+            for i, q in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = q.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                        codes[i] = q.wait()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    out0 = captured[0] if captured else ""
     lines = [l for l in out0.splitlines() if l.startswith("{")]
     for l in out0.splitlines():
         if not l.startswith("{"):
@@ -257,7 +304,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
-                    help="skip the timing of the other single-GPU configurations after the headline (N = 1 only)")
+                    help="skip the timing of the other configurations after the headline")
+    ap.add_argument("--other-sizes", default=None,
+                    help="sizes of the other configurations as n3,batch3,n4,batch4,log_n5 (default 4096,65536,131072,64,28; the CPU "
+                         "rehearsal uses 256,8,1024,4,12)")
     ap.add_argument("--lib", default=None, help="diagnostic: load this build of the library instead of the shipped one")
     ap.add_argument("--no-verify", action="store_true", help="diagnostic: skip the result checks (ablated builds)")
     ap.add_argument("--rehearse-cpu", action="store_true",
@@ -339,6 +389,7 @@ def main():
             sync()
 
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
+    collective_info = None
     if world > 1:
         # the first collectives create the communicator (seconds): do that before the ramp, so that the barrier in
         # front of the timed region is a short one and the GPUs enter it warm
@@ -346,6 +397,12 @@ def main():
         tw = torch.zeros(1, dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         sync()
+        # attestation that the ranks really talk to one another: every rank contributes a one, the sum must be the world size
+        ones = torch.ones(1, dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(ones)
+        sync()
+        collective_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "all_reduce_of_ones": float(ones.item()),
+                           "devices": torch.cuda.device_count() if not cpu else 0}
     # Clock ramp, untimed and declared in the output line: on MI355X the first ~25 ms of a sustained integer load
     # run up to 40 % slower than the steady state that follows (per-launch trace in profiles/), so a short
     # benchmark would time the transient instead of the throughput.
@@ -419,6 +476,24 @@ def main():
         copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
 
+    # The other configurations, timed by the same rank processes (collective across the ranks: every rank takes part).
+    others = None
+    run_others = not args.no_other_configs and (cpu or not args.lib)
+    if run_others:
+        from ntt_amd.workloads import RankClock
+        del a_sets, b_sets, ws
+        if not cpu:
+            torch.cuda.empty_cache()
+        if args.other_sizes:
+            v = [int(x) for x in args.other_sizes.split(",")]
+        else:
+            v = [256, 8, 1024, 4, 12] if cpu else [4096, 65536, 131072, 64, 28]
+        sizes = {"c3": {"n": v[0], "batch": v[1]}, "c4": {"n": v[2], "batch": v[3]}, "c5": {"log_n": v[4]}}
+        if world > 1:
+            dist.barrier()
+        clock = RankClock(torch, dist if world > 1 else None, dev, comm_dev)
+        others = other_configurations(torch, dist, lib, clock, sizes)
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * B / (elapsed / args.steps)
@@ -473,10 +548,10 @@ def main():
                 "roofline": roofline}
         if cpu:
             line["rehearsal"] = "CPU twin over gloo: control-flow rehearsal, not a measurement"
-        if world == 1 and not cpu and not args.no_other_configs and not args.lib:
-            del a_sets, b_sets, out, ws
-            torch.cuda.empty_cache()
-            line["other_configs"] = other_configurations(torch, lib, stream)
+        if collective_info is not None:
+            line["rccl"] = collective_info
+        if others is not None:
+            line["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline and not cpu:
             line["cpu_baseline"] = cpu_baseline(n, p)
         print(json.dumps(line), flush=True)

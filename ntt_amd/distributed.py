@@ -17,7 +17,7 @@ between the residue products and the merge.
 
 All arithmetic runs in the library's kernels through its C ABI; torch provides device memory and the collectives (RCCL on
 GPUs, gloo on CPU in the tests).  On a GPU with RCCL everything is ordered on torch's current stream and the host never
-waits between the steps; any other backend on a GPU moves device memory from the host side, so the exchange is then
+waits between the steps; with any other backend on a GPU (rehearsals over gloo) the exchange goes through host memory,
 bracketed by device synchronisation."""
 import numpy as np
 
@@ -91,13 +91,14 @@ class CrtDistributed:
         else:
             if nu:
                 self.send.copy_(self.local[:nu].view(nu, self.world, self.Lw).transpose(0, 1))
-            self._host_wait()
-            if self.equal_split:
-                self.dist.all_to_all_single(self.recv.view(-1), self.send.view(-1))
-            else:
-                self.dist.all_to_all_single(self.recv.view(-1), self.send.view(-1), output_split_sizes=self.out_splits,
-                                            input_split_sizes=self.in_splits)
-            self._host_wait()
+            splits = {} if self.equal_split else {"output_split_sizes": self.out_splits, "input_split_sizes": self.in_splits}
+            if self.stream_ordered:
+                self.dist.all_to_all_single(self.recv.view(-1), self.send.view(-1), **splits)
+            else:                                    # through host memory, bracketed by device synchronisation
+                host_in = self.torch.empty(self.recv.numel(), dtype=self.torch.int32)
+                self.dist.all_to_all_single(host_in, self.send.view(-1).cpu(), **splits)
+                self.recv.view(-1).copy_(host_in)
+                self._host_wait()
             recv = self.recv
         # 3. merge this rank's slice of the four residue planes [4][batch][Lw]
         count = self.batch * self.Lw
@@ -109,7 +110,13 @@ class CrtDistributed:
         t = self.torch
         if self.world == 1:
             return out[:, :2 * self.n - 1]
-        self._host_wait()
+        if not self.stream_ordered:                  # through host memory
+            host = out.cpu()
+            parts = [t.empty_like(host) for _ in range(self.world)]
+            self.dist.all_gather(parts, host)
+            if not all_ranks and self.rank != 0:
+                return None
+            return t.stack(parts, dim=1).reshape(self.batch, self.Lp)[:, :2 * self.n - 1].to(self.device)
         if all_ranks:
             parts = [t.empty_like(out) for _ in range(self.world)]
             self.dist.all_gather(parts, out)
@@ -118,7 +125,6 @@ class CrtDistributed:
             self.dist.gather(out, parts, dst=0)
             if self.rank != 0:
                 return None
-        self._host_wait()
         return t.stack(parts, dim=1).reshape(self.batch, self.Lp)[:, :2 * self.n - 1]
 
 

@@ -56,6 +56,32 @@ def plan_shape(n, world):
     return log_total, log_rows, log_total - log_rows
 
 
+class _HostStagedExchange:
+    """The exchange of one row piece for process groups that cannot take device memory on the device stream (gloo with GPU
+    tensors: rehearsals of the rank logic on a box with fewer GPUs than ranks): the chunks travel through host tensors,
+    bracketed by device synchronisation.  Same interface as a pending transfer: wait()."""
+
+    def __init__(self, fs, send, recv, lo, hi):
+        t, d = fs.torch, fs.dist
+        t.cuda.synchronize(fs.device)                    # the kernels that produced `send` have finished
+        recv[fs.rank, lo:hi].copy_(send[fs.rank, lo:hi])
+        self.fs, self.recv, self.lo, self.hi = fs, recv, lo, hi
+        self.host_out = {g: send[g, lo:hi].cpu() for g in range(fs.world) if g != fs.rank}
+        self.host_in = {g: t.empty_like(v) for g, v in self.host_out.items()}
+        ops = []
+        for g in self.host_out:
+            ops.append(d.P2POp(d.irecv, self.host_in[g], g))
+            ops.append(d.P2POp(d.isend, self.host_out[g], g))
+        self.works = d.batch_isend_irecv(ops) if ops else []
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        for g, v in self.host_in.items():
+            self.recv[g, self.lo:self.hi].copy_(v)
+        self.fs.torch.cuda.synchronize(self.fs.device)
+
+
 class FourStep:
     """Four-step product context of one rank.  lib: NttLibrary; dist: torch.distributed or None."""
 
@@ -113,7 +139,7 @@ class FourStep:
         need no packing and the same code runs on gloo.  Returns the pending transfers."""
         lo, hi = rows
         if not self.stream_ordered:
-            self.torch.cuda.synchronize(self.device)          # the kernels that produced `send` have finished
+            return [_HostStagedExchange(self, send, recv, lo, hi)]
         recv[self.rank, lo:hi].copy_(send[self.rank, lo:hi])
         ops = []
         for g in range(self.world):
@@ -126,8 +152,6 @@ class FourStep:
         """Completion of pending transfers: ordered on the stream with RCCL, waited for by the host otherwise."""
         for w in works:
             w.wait()
-        if works and not self.stream_ordered:
-            self.torch.cuda.synchronize(self.device)
 
     def _row_pieces(self):
         per = self.Rl // self.chunks
@@ -233,9 +257,14 @@ class FourStep:
         """The same, staying on the device: int64 tensor of 2n-1 words."""
         t = self.torch
         slab = slab.contiguous()
+        if self.world > 1 and not self.stream_ordered:       # through host memory (see _HostStagedExchange)
+            host = slab.cpu()
+            parts = [t.empty_like(host) for _ in range(self.world)]
+            self.dist.all_gather(parts, host)
+            if not all_ranks and self.rank != 0:
+                return None
+            return t.cat(parts, dim=1).to(self.device).reshape(-1)[: 2 * self.n - 1]
         if self.world > 1:
-            if not self.stream_ordered:
-                t.cuda.synchronize(self.device)
             if all_ranks:
                 parts = [t.empty_like(slab) for _ in range(self.world)]
                 self.dist.all_gather(parts, slab)
@@ -244,8 +273,6 @@ class FourStep:
                 self.dist.gather(slab, parts, dst=0)
                 if self.rank != 0:
                     return None
-            if not self.stream_ordered:
-                t.cuda.synchronize(self.device)
             full = t.cat(parts, dim=1)
         else:
             full = slab

@@ -50,3 +50,38 @@ def evaluate(coeffs, x, p, block=1 << 20, rows_per_pass=64):
         acc = (acc + s % p * scale) % p
         scale = scale * xb % p
     return acc
+
+
+def evaluate_rows(coeffs, x, p, rows_per_pass=8):
+    """[A_r(x) mod p for every row r] of a 2-D int64 tensor of canonical residues (Python ints)."""
+    dev = coeffs.device
+    rows, n = coeffs.shape
+    pw = powers(x, 1 << max(0, (n - 1).bit_length()), p, dev)[:n]
+    out = []
+    for lo in range(0, rows, rows_per_pass):
+        t = mulmod(coeffs[lo:lo + rows_per_pass], pw[None, :], p)
+        lo_half = (t & 0x3FFFFFFF).sum(dim=1); hi_half = (t >> 30).sum(dim=1)
+        out += [(int(l) + (int(h) << 30)) % p for l, h in zip(lo_half.tolist(), hi_half.tolist())]
+    return out
+
+
+def evaluate_slab(slab, col0, C, x, p, rows=None, elems_per_pass=1 << 24):
+    """This slab's share of A(x) for a coefficient vector laid out as an R x C matrix (element i = j + C*r at row r, column j):
+    sum over the slab's rows r < rows and columns j = col0 .. col0 + Cl - 1 of slab[r][j - col0] * x^(j + C*r) mod p."""
+    dev = slab.device
+    R, Cl = slab.shape
+    rows = R if rows is None else min(rows, R)
+    pw = powers(x, 1 << max(0, (Cl - 1).bit_length()), p, dev)[:Cl]
+    pw = mulmod(pw, pow(int(x), int(col0), p), p)
+    per = max(1, elems_per_pass // Cl)
+    row_vals = []
+    for lo in range(0, rows, per):
+        t = mulmod(slab[lo:min(rows, lo + per)], pw[None, :], p)
+        lo_half = (t & 0x3FFFFFFF).sum(dim=1); hi_half = (t >> 30).sum(dim=1)
+        row_vals += [(int(l) + (int(h) << 30)) % p for l, h in zip(lo_half.tolist(), hi_half.tolist())]
+    xc = pow(int(x), int(C), p)
+    acc, scale = 0, 1
+    for v in row_vals:
+        acc = (acc + v * scale) % p
+        scale = scale * xc % p
+    return acc

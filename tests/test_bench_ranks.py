@@ -37,6 +37,14 @@ def test_gpus_flag_alone_starts_that_many_ranks():
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "batch-sharded x2" and "rehearsal" in d
     assert d["verified_vs_oracle"] is True and d["verification"]["all_ranks_ok"] is True
     assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6   # whole-job rate over both ranks
+    # the ranks attest that they talk to one another, and the same processes time the other configurations across the ranks:
+    # batch-sharded small and large-modulus products, the CRT work split by (prime, row) with its all-to-all, the four-step product
+    assert d["rccl"] == {"backend": "gloo", "world_size": 2, "all_reduce_of_ones": 2.0, "devices": 0}
+    others = d["other_configs"]
+    assert len(others) == 4 and all(o["n_gpus"] == 2 and o["verified"] is True and "roofline" in o for o in others), others
+    assert [o["scaling"] for o in others] == ["weak", "weak", "strong", "strong"]
+    assert others[2]["exchange"]["collective"] == "all_to_all_single" and others[3]["exchange"]["per_product"] == 3
+    assert all(len(o["rank_ms"]) == 2 and o["rank_ms"][0] <= o["rank_ms"][1] for o in others)
 
 
 def test_launcher_form_and_rank_mismatch():

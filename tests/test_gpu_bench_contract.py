@@ -40,10 +40,17 @@ def test_bench_line_has_the_contract_keys():
     ver = d["verification"]
     assert ver["all_products_evaluation_identity"] is True and ver["rows_checked"] == 8 and ver["oracle_ok"] is True
     # the other single-GPU configurations are timed beside the headline, each with a spot check of its result
+    # (the fifth is the n = 2^28 product again in its explicit four-step form, the one that shards over ranks)
     others = d["other_configs"]
-    assert len(others) == 4 and all("error" not in o for o in others), others
-    assert all(o["spot_check"] is True and o["poly_mults_per_s"] > 0 for o in others)
+    assert len(others) == 5 and all("error" not in o for o in others), others
+    assert all(o["verified"] is True and o["poly_mults_per_s"] > 0 for o in others)
     assert others[1]["kernels"].startswith("k64_") and others[2]["kernels"].endswith("k_crt_merge")
+    for o in others:     # every configuration prices itself against the HBM roofline, on the model's bytes and on the moved ones
+        r = o["roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1.2 and 0 < r["frac_moved"] < 1.2
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "issue" in others[0]["roofline"] and 0 < others[0]["roofline"]["issue"]["frac"] < 1.2
+    assert abs(others[4]["ms_per_call"] / others[3]["ms_per_call"] - 1) < 0.10     # four-step form at world 1 = the direct product
 
 
 def test_more_gpus_than_the_node_has_is_an_error_not_a_smaller_run():
