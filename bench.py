@@ -68,18 +68,16 @@ def load_traffic(kernel, batch):
     """(HBM bytes per launch of `kernel`, source) from the newest committed PMC summary (profiles/traffic_*.json), which
     was collected at the batch size recorded in it (256 when absent); traffic is proportional to the batch.  The figure
     is static: it describes the kernels as they were when that profile was taken, not this run."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")))
-    if not files:
-        return None, None
-    try:
-        with open(files[-1]) as f:
-            d = json.load(f)
-        per_launch = d.get(kernel, {}).get("hbm_bytes_per_launch")
-        if per_launch is None:
-            return None, None
-        return per_launch * batch / d.get("_meta", {}).get("batch", 256), f"profiles/{os.path.basename(files[-1])} (static, rocprofv3 --pmc)"
-    except Exception:
-        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")), reverse=True):   # newest summary that has this kernel
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            per_launch = d.get(kernel, {}).get("hbm_bytes_per_launch")
+            if per_launch is not None and d.get("_meta", {}).get("n", 131072) == 131072:
+                return per_launch * batch / d.get("_meta", {}).get("batch", 256), f"profiles/{os.path.basename(path)} (static, rocprofv3 --pmc)"
+        except Exception:
+            continue
+    return None, None
 
 
 def valu_roofline(kernel, batch, avg_ms):

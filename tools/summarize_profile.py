@@ -6,7 +6,7 @@
                            gfx950 corrections: both counters are in KiB; FETCH_SIZE tallies 128-byte
                            requests of wide coalesced reads at 64 bytes, so it is doubled; WRITE_SIZE
                            is exact.
-usage: tools/summarize_profile.py gpurun_out/prof_<tag> <tag> [batch per launch, default 256]"""
+usage: tools/summarize_profile.py gpurun_out/prof_<tag> <tag> [batch per launch, default 256] [n, default 131072]"""
 import collections
 import csv
 import glob
@@ -21,7 +21,7 @@ def short(name):
     return m.group(1) if m else None
 
 
-def main(src, tag, batch=256):
+def main(src, tag, batch=256, n=131072):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dst = os.path.join(root, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -69,10 +69,10 @@ def main(src, tag, batch=256):
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             rd, wr = d["FETCH_SIZE"] * 1024 * 2, d["WRITE_SIZE"] * 1024
             traffic[k] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
-    traffic["_meta"] = {"batch": batch, "n": 131072, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes"}
+    traffic["_meta"] = {"batch": batch, "n": n, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes"}
     json.dump(traffic, open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(traffic, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 256)
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 256, int(sys.argv[4]) if len(sys.argv) > 4 else 131072)
