@@ -320,26 +320,75 @@ size_t pipeline_workspace_bytes(int logL, size_t batch) {
     return 2 * batch * ((size_t)1 << logL) * sizeof(uint32_t);
 }
 
-template <int Q, bool LZ, bool FULL, int MINW, typename TIn, typename TOut>
-void launch_multipass_v(const Plan& pl, const TIn* a, const TIn* b, TOut* out, int n, size_t batch, size_t sa, size_t sb,
-                        size_t so, uint32_t* tmpA, uint32_t* tmpB, hipStream_t st) {
+// forward column passes of both operands and the fused core: leaves the block-wise product spectrum's inverse core output
+// in tmpA (what the inverse column pass reads)
+template <int Q, bool LZ, bool FULL, int MINW, typename TIn>
+void launch_fwd_core_v(const Plan& pl, const TIn* a, const TIn* b, int n, size_t batch, size_t sa, size_t sb, uint32_t* tmpA,
+                       uint32_t* tmpB, hipStream_t st) {
     const int C = CORE_N;
     const unsigned chunks = C / 256;
     NTT_LAUNCH_P("k_fwd_strided", (k_fwd_strided<Q, LZ, true, FULL, MINW, TIn>), dim3((unsigned)(chunks * batch), 1, 2), dim3(256),
                  st, a, b, sa, sb, n, tmpA, tmpB, C, pl.T1, pl.h.fc);
     NTT_LAUNCH_P("k_core_mul", (k_core_mul<LZ>), dim3((unsigned)(batch << Q)), dim3(CORE_T), st, (const uint32_t*)tmpA,
                  (const uint32_t*)tmpB, tmpA, pl.h.fc, pl.core);
+}
+
+template <int Q, bool LZ, bool FULL, int MINW, typename TIn, typename TOut>
+void launch_multipass_v(const Plan& pl, const TIn* a, const TIn* b, TOut* out, int n, size_t batch, size_t sa, size_t sb,
+                        size_t so, uint32_t* tmpA, uint32_t* tmpB, hipStream_t st) {
+    const int C = CORE_N;
+    const unsigned chunks = C / 256;
+    launch_fwd_core_v<Q, LZ, FULL, MINW, TIn>(pl, a, b, n, batch, sa, sb, tmpA, tmpB, st);
     NTT_LAUNCH_P("k_inv_strided", (k_inv_strided<Q, LZ, true, FULL, MINW, TOut>), dim3((unsigned)(chunks * batch)), dim3(256), st,
                  (const uint32_t*)tmpA, out, so, 2 * n - 1, C, pl.T3, pl.h.fc);
 }
+
+constexpr int multipass_minw(int Q) { return Q == 6 ? 2 : 1; }
 
 template <int Q, bool LZ, typename TIn, typename TOut>
 void launch_multipass(const Plan& pl, const TIn* a, const TIn* b, TOut* out, int n, size_t batch, size_t sa, size_t sb,
                       size_t so, uint32_t* tmpA, uint32_t* tmpB, hipStream_t st) {
     const bool full = (2 * (size_t)n == ((size_t)CORE_N << Q));
-    constexpr int MINW = Q == 6 ? 2 : 1;
+    constexpr int MINW = multipass_minw(Q);
     if (full) launch_multipass_v<Q, LZ, true, MINW>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st);
     else launch_multipass_v<Q, LZ, false, MINW>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st);
+}
+
+// The four-prime route with the recombination fused into the inverse column pass (transform lengths 2^14 .. 2^18): per
+// prime the forward column passes and the core, its result left in that prime's plane; then one launch runs the inverse
+// column pass of all four primes and merges in LDS.
+#ifndef NTT_CRT_INV_CW
+#define NTT_CRT_INV_CW 64
+#endif
+constexpr int CRT_INV_CW = NTT_CRT_INV_CW;   // columns per workgroup of k_inv_strided_crt (4 * CW threads)
+
+template <int Q>
+void launch_crt_multipass(Plan* const (&pl)[4], const uint64_t* a, const uint64_t* b, uint64_t* out, int n, size_t batch, size_t sa,
+                          size_t sb, size_t so, uint32_t* planes, size_t plane_stride, uint32_t* tmpB, const CrtConsts& c,
+                          hipStream_t st) {
+    const bool full = (2 * (size_t)n == ((size_t)CORE_N << Q));
+    constexpr int MINW = multipass_minw(Q);
+    CrtInvArgs args;
+    for (int i = 0; i < 4; ++i) {
+        uint32_t* tmpA = planes + i * plane_stride;
+        if (pl[i]->h.lazy) {
+            if (full) launch_fwd_core_v<Q, true, true, MINW>(*pl[i], a, b, n, batch, sa, sb, tmpA, tmpB, st);
+            else launch_fwd_core_v<Q, true, false, MINW>(*pl[i], a, b, n, batch, sa, sb, tmpA, tmpB, st);
+        } else {
+            if (full) launch_fwd_core_v<Q, false, true, MINW>(*pl[i], a, b, n, batch, sa, sb, tmpA, tmpB, st);
+            else launch_fwd_core_v<Q, false, false, MINW>(*pl[i], a, b, n, batch, sa, sb, tmpA, tmpB, st);
+        }
+        args.src[i] = tmpA;
+        args.T3[i] = pl[i]->T3;
+        args.fc[i] = pl[i]->h.fc;
+    }
+    const unsigned grid = (unsigned)((CORE_N / CRT_INV_CW) * batch);
+    if (full)
+        NTT_LAUNCH_P("k_inv_strided_crt", (k_inv_strided_crt<Q, CRT_INV_CW, true>), dim3(grid), dim3(4 * CRT_INV_CW), st, args, out, so,
+                     2 * n - 1, CORE_N, c);
+    else
+        NTT_LAUNCH_P("k_inv_strided_crt", (k_inv_strided_crt<Q, CRT_INV_CW, false>), dim3(grid), dim3(4 * CRT_INV_CW), st, args, out, so,
+                     2 * n - 1, CORE_N, c);
 }
 
 template <bool LZ, typename TIn, typename TOut>
@@ -405,15 +454,30 @@ unsigned grid_rows(size_t batch) { return (unsigned)(batch < 65535 ? batch : 655
 
 int make_crt_consts(uint64_t p, CrtConsts* c) {
     if (p < 2) return fail(NTT_ERR_ARG, "modulus must be at least 2");
-    CrtHost h = crt_host_consts();
+    // the primes of the basis in ascending order (Garner's digits then never need a negative intermediate)
+    int order[4] = {0, 1, 2, 3};
+    std::sort(order, order + 4, [](int x, int y) { return kCrtPrimes[x] < kCrtPrimes[y]; });
+    uint64_t m[4];
     for (int i = 0; i < 4; ++i) {
-        c->q[i] = kCrtPrimes[i];
-        c->nq[i] = h_neg_inv32(kCrtPrimes[i]);
-        c->minv_m[i] = h_mont(h.Mi_inv[i], kCrtPrimes[i]);
-        c->mi_lo[i] = (uint64_t)h.Mi[i];
-        c->mi_hi[i] = (uint32_t)(h.Mi[i] >> 64);
+        m[i] = kCrtPrimes[order[i]];
+        c->m[i] = (uint32_t)m[i];
+        c->nm[i] = h_neg_inv32((uint32_t)m[i]);
+        c->src[i] = order[i];
     }
-    c->M_lo = (uint64_t)h.M; c->M_hi = (uint64_t)(h.M >> 64);
+    auto inv = [](uint64_t x, uint64_t q) { return h_powmod(x % q, q - 2, q); };
+    c->k1 = h_mont((uint32_t)inv(m[0], m[1]), (uint32_t)m[1]);
+    c->c2 = h_mont((uint32_t)(m[0] % m[2]), (uint32_t)m[2]);
+    c->k2 = h_mont((uint32_t)inv(h_mulmod(m[0], m[1], m[2]), m[2]), (uint32_t)m[2]);
+    c->c31 = h_mont((uint32_t)(m[0] % m[3]), (uint32_t)m[3]);
+    c->c32 = h_mont((uint32_t)h_mulmod(m[0], m[1], m[3]), (uint32_t)m[3]);
+    c->k3 = h_mont((uint32_t)inv(h_mulmod(h_mulmod(m[0], m[1], m[3]), m[2], m[3]), m[3]), (uint32_t)m[3]);
+    // tail: x mod p from the digits
+    c->fp = (double)p <= FIELDD_MAX_P ? 1 : 0;
+    c->pd = (double)p;
+    c->ud = 1.0 / (double)p;
+    auto balanced = [p](uint64_t v) { v %= p; return v > p / 2 ? -(double)(p - v) : (double)v; };
+    const uint64_t e1 = m[0] % p, e2 = h_mulmod(e1, m[1] % p, p), e3 = h_mulmod(e2, m[2] % p, p);
+    c->d1 = balanced(e1); c->d2 = balanced(e2); c->d3 = balanced(e3);
     c->p = p;
     c->shift = __builtin_clzll(p);
     c->d = p << c->shift;
@@ -434,6 +498,12 @@ bool direct_path_ok(uint64_t p, int logL) {
     const bool ok = modulus_is_ntt_friendly(p, logL);
     if (memo.size() < 4096) memo[key] = ok;
     return ok;
+}
+
+// NTT_CRT_MERGE=separate keeps the recombination a pass of its own (A/B measurements and tests of the stand-alone merge kernel)
+bool crt_fused_merge_allowed() {
+    static const bool v = [] { const char* e = getenv("NTT_CRT_MERGE"); return !(e && strcmp(e, "separate") == 0); }();
+    return v;
 }
 
 size_t crt_workspace_bytes(int logL, size_t batch) {
@@ -459,14 +529,35 @@ int crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, uint64
     const size_t pipe = pipeline_workspace_bytes(logL, batch);
     uint32_t* res = (uint32_t*)((char*)ws + pipe);
     const size_t res_stride = batch * L;
-    for (int i = 0; i < 4; ++i) {
-        int rc = product_device<uint64_t, uint32_t>(dev, a, b, res + i * res_stride, n, kCrtPrimes[i], batch, sa, sb, L, ws,
-                                                    pipe, st);
-        if (rc != NTT_OK) return rc;
-    }
     CrtConsts c;
     int rc = make_crt_consts(p, &c);
     if (rc != NTT_OK) return rc;
+    // multi-pass lengths: the merge rides on the inverse column pass.  The basis is fixed: its second prime is the one
+    // kept fully reduced, the kernel relies on that
+    Plan* pl[4];
+    bool multipass = true;
+    for (int i = 0; i < 4; ++i) {
+        if ((rc = get_plan(dev, kCrtPrimes[i], logL, &pl[i])) != NTT_OK) return rc;
+        multipass = multipass && pl[i]->h.kind == PLAN_MULTIPASS && pl[i]->h.lazy == (i != 1);
+    }
+    if (multipass && crt_fused_merge_allowed()) {
+        // workspace: [tmpB | unused half of the pipeline area][four planes]; a prime's own plane takes the place of tmpA
+        uint32_t* tmpB = (uint32_t*)ws;
+        switch (pl[0]->h.Q) {
+            case 2: launch_crt_multipass<2>(pl, a, b, out, n, batch, sa, sb, so, res, res_stride, tmpB, c, st); break;
+            case 3: launch_crt_multipass<3>(pl, a, b, out, n, batch, sa, sb, so, res, res_stride, tmpB, c, st); break;
+            case 4: launch_crt_multipass<4>(pl, a, b, out, n, batch, sa, sb, so, res, res_stride, tmpB, c, st); break;
+            case 5: launch_crt_multipass<5>(pl, a, b, out, n, batch, sa, sb, so, res, res_stride, tmpB, c, st); break;
+            case 6: launch_crt_multipass<6>(pl, a, b, out, n, batch, sa, sb, so, res, res_stride, tmpB, c, st); break;
+            default: return fail(NTT_ERR_ARG, "unsupported strided radix");
+        }
+        HIP_TRY(hipGetLastError());
+        return NTT_OK;
+    }
+    for (int i = 0; i < 4; ++i) {
+        rc = product_device<uint64_t, uint32_t>(dev, a, b, res + i * res_stride, n, kCrtPrimes[i], batch, sa, sb, L, ws, pipe, st);
+        if (rc != NTT_OK) return rc;
+    }
     const size_t count = (size_t)(2 * n - 1);
     NTT_LAUNCH_P("k_crt_merge", k_crt_merge, dim3((unsigned)((count + 255) / 256), grid_rows(batch)), dim3(256), st, (const uint32_t*)res,
                res_stride, out, count, batch, so, L, c);
@@ -2182,7 +2273,9 @@ int ntt_describe_plan(int n, uint64_t p, char* buf, size_t buf_len) {
     const Route route = choose_route(p, (size_t)n, &why);
     const char* pipe = logL <= 12 ? ((logL >= 5 && p < (1ull << 31) && (p - 1) % 64 == 0) ? "k_small16" : "k_small") : logL == 13 ? "k_fused8192" : "k_fwd_strided,k_core_mul,k_inv_strided";
     if (route == ROUTE_DIRECT32) s = pipe;
-    else if (route == ROUTE_CRT) s = std::string("4x(") + pipe + "),k_crt_merge";
+    else if (route == ROUTE_CRT)
+        s = (logL >= 14 && crt_fused_merge_allowed()) ? std::string("4x(k_fwd_strided,k_core_mul),k_inv_strided_crt")
+                                                      : std::string("4x(") + pipe + "),k_crt_merge";
     else if (route == ROUTE_FIELD64 || route == ROUTE_WIDECRT) {
         // the launches of one product in the 64-bit field, in order of first use
         const std::vector<Step64> steps = plan_steps(logL, 1, 1);

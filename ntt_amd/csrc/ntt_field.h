@@ -45,6 +45,13 @@ struct FieldConsts {
 #else
 #define NTT_OPAQUE(x) asm volatile("" : "+r"(x))
 #endif
+// a value that is the same in every lane of a wavefront, moved to a scalar register (so that what is indexed with it --
+// kernel arguments, constants -- is fetched by scalar loads)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NTT_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define NTT_UNIFORM(x) (x)
+#endif
 
 // (T + m*p) / 2^32 with m = T*np mod 2^32.  For T < 2^32 * p the result is in [0, 2p).
 NTT_HD uint32_t redc_lazy(uint64_t T, uint32_t p, uint32_t np) {

@@ -22,6 +22,7 @@
 // :171-173, residue step :206-209, CRT merge :216-223.
 #pragma once
 #include "ntt_field.h"
+#include "ntt_field64.h"
 
 namespace nttamd {
 
@@ -273,14 +274,13 @@ __device__ __forceinline__ void fwd_column(const TIn* src, int n_valid, uint32_t
     }
 }
 
-// inv_column: mirror of fwd_column.  FINAL: results are reduced to [0,p) and only indices < n_out
-// are stored; otherwise the block is written back in place layout (uint32, lazy range).
-template <int Q, bool LZ, bool FINAL, bool FULL, typename TOut>
-__device__ __forceinline__ void inv_column(const uint32_t* src, TOut* dst, int n_out, int C, const uint32_t* T3,
-                                           const FieldConsts& fc, int j) {
+// inv_column_regs: mirror of fwd_column up to the registers: x[r] = value of row r of column j after the twiddles and the
+// radix-2^Q inverse, in the inverse side's lazy range.
+template <int Q, bool LZ>
+__device__ __forceinline__ void inv_column_regs(const uint32_t* src, int C, const uint32_t* T3, const FieldConsts& fc, int j,
+                                                uint32_t (&x)[1 << Q]) {
     constexpr int R = 1 << Q;
     const Field<LZ> f(fc);
-    uint32_t x[R];
     constexpr int G = R / 4;
     constexpr int SG = G < 4 ? G : 4;
     constexpr int NS = G / SG;
@@ -316,6 +316,17 @@ __device__ __forceinline__ void inv_column(const uint32_t* src, TOut* dst, int n
 #ifndef NTT_ABLATE_STRIDED_MATH
     dit_reg<Q, LZ, true>(x, f, fc.rootI);
 #endif
+}
+
+// inv_column: the inverse column pass of one column.  FINAL: results are reduced to [0,p) and only indices < n_out
+// are stored; otherwise the block is written back in place layout (uint32, lazy range).
+template <int Q, bool LZ, bool FINAL, bool FULL, typename TOut>
+__device__ __forceinline__ void inv_column(const uint32_t* src, TOut* dst, int n_out, int C, const uint32_t* T3,
+                                           const FieldConsts& fc, int j) {
+    constexpr int R = 1 << Q;
+    const Field<LZ> f(fc);
+    uint32_t x[R];
+    inv_column_regs<Q, LZ>(src, C, T3, fc, j, x);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int idx = j + C * r;
@@ -581,19 +592,26 @@ __global__ void __launch_bounds__(CORE_T) k_small16(const TIn* A, const TIn* Bp,
 }
 
 // ---------------------------------------------------------------------------
-// k_crt_merge: 128-bit CRT recombination, one thread per coefficient.
-//   S = sum_i M_i * ((r_i * M_i^-1) mod p_i);  S mod M;  then mod p.
-// Same value as the reference loop (main_naive.cc:216-223, main_mpi_CRT.cc:512-522): the sum
-// of four terms < M is brought below M by subtracting 2M and M conditionally instead of a
-// 128-bit division, and the final "mod p" uses a reciprocal-based 128-by-64 remainder.
+// CRT recombination of one coefficient from its four canonical residues s[0..3] (moduli in ascending order: s[i] belongs
+// to prime src[i] of the basis):
+// the value x in [0, M) with x = r_i mod q_i, then x mod p.  The reference forms S = sum_i M_i * ((r_i * M_i^-1) mod q_i),
+// S mod M and then mod p with 128-bit divisions (main_naive.cc:216-223, main_mpi_CRT.cc:512-522); x is unique, so any exact
+// way to it gives the same bits.  Here: mixed-radix (Garner) digits with the primes taken in ascending order m0 < m1 < m2 <
+// m3 -- six modular multiplies in 32-bit Montgomery arithmetic, x = v0 + m0 (v1 + m1 (v2 + m2 v3)) -- and then
+//   p <= 1.5e15:  x mod p = v0 + (m0 mod p) v1 + (m0 m1 mod p) v2 + (m0 m1 m2 mod p) v3 in exact double-precision
+//                 arithmetic (the multiply of ntt_field64.h: |v_i| < 2^31 times a balanced constant, quotient below 2^31);
+//   larger p:     x as a 128-bit integer by Horner's rule, then a reciprocal-based 128-by-64 remainder (Moeller-Granlund).
 // ---------------------------------------------------------------------------
 struct CrtConsts {
-    uint32_t q[4];        // the four NTT primes
-    uint32_t nq[4];       // -q^-1 mod 2^32
-    uint32_t minv_m[4];   // Montgomery form of (M/q_i)^-1 mod q_i
-    uint64_t mi_lo[4];    // M/q_i, low 64 bits
-    uint32_t mi_hi[4];    // M/q_i, bits 64..95
-    uint64_t M_lo, M_hi;  // M = product of the four primes (< 2^120)
+    uint32_t m[4];        // the four NTT primes in ascending order
+    uint32_t nm[4];       // -m^-1 mod 2^32
+    int src[4];           // m[i] is prime src[i] of the basis
+    uint32_t k1;          // Montgomery form mod m1 of m0^-1
+    uint32_t c2, k2;      // mod m2: m0, (m0 m1)^-1
+    uint32_t c31, c32, k3;  // mod m3: m0, m0 m1, (m0 m1 m2)^-1
+    int fp;               // p <= 1.5e15: the double-precision tail
+    double pd, ud;        // p, 1/p
+    double d1, d2, d3;    // m0, m0 m1, m0 m1 m2 mod p, balanced
     uint64_t p;           // final modulus
     uint64_t d;           // p << shift (top bit set)
     uint64_t v;           // floor((2^128-1)/d) - 2^64
@@ -613,33 +631,95 @@ __device__ __forceinline__ uint64_t rem_2by1(uint64_t u1, uint64_t u0, uint64_t 
     return r >> shift;
 }
 
+__device__ __forceinline__ uint64_t crt_merge_value(const uint32_t (&s)[4], const CrtConsts& c) {
+    // Garner digits.  Every difference is kept non-negative by adding multiples of the modulus; the primes are below
+    // 2^31 and ascending, so the sums stay below 2^32 (3 m3 < 3.7e9).
+    const uint32_t s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3];
+    const uint32_t v0 = s0;
+    const uint32_t v1 = csub(redc_lazy((uint64_t)(s1 + c.m[1] - v0) * c.k1, c.m[1], c.nm[1]), c.m[1]);
+    const uint32_t u2 = csub(redc_lazy((uint64_t)v1 * c.c2, c.m[2], c.nm[2]), c.m[2]);
+    const uint32_t v2 = csub(redc_lazy((uint64_t)(s2 + 2 * c.m[2] - v0 - u2) * c.k2, c.m[2], c.nm[2]), c.m[2]);
+    const uint32_t u3 = csub(redc_lazy((uint64_t)v1 * c.c31 + (uint64_t)v2 * c.c32, c.m[3], c.nm[3]), c.m[3]);
+    const uint32_t v3 = csub(redc_lazy((uint64_t)(s3 + 2 * c.m[3] - v0 - u3) * c.k3, c.m[3], c.nm[3]), c.m[3]);
+    if (c.fp) {
+        FieldDConsts fdc{};
+        fdc.p = c.pd; fdc.u = c.ud;
+        const FieldD f(fdc);
+        const double acc = (double)v0 + f.mulw((double)v1, c.d1) + f.mulw((double)v2, c.d2) + f.mulw((double)v3, c.d3);
+        return f.canon(acc);
+    }
+    // x = ((v3 m2 + v2) m1 + v1) m0 + v0 < M < 2^119
+    const uint64_t t1 = (uint64_t)v3 * c.m[2] + v2;
+    uint64_t lo = t1 * c.m[1], hi = __umul64hi(t1, (uint64_t)c.m[1]);
+    lo += v1; hi += lo < v1 ? 1u : 0u;
+    uint64_t x_lo = lo * c.m[0], x_hi = __umul64hi(lo, (uint64_t)c.m[0]) + hi * c.m[0];
+    x_lo += v0; x_hi += x_lo < v0 ? 1u : 0u;
+    const uint64_t r1 = rem_2by1(0, x_hi, c.d, c.v, c.shift);
+    return rem_2by1(r1, x_lo, c.d, c.v, c.shift);
+}
+
 __global__ void __launch_bounds__(256) k_crt_merge(const uint32_t* res, size_t res_stride, uint64_t* out, size_t count,
                                                    size_t rows, size_t out_stride, size_t row_stride, CrtConsts c) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
     for (size_t row = blockIdx.y; row < rows; row += gridDim.y) {   // grid.y is capped at the launch limit
-        uint64_t s_lo = 0, s_hi = 0;
+        uint32_t r[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t r = res[(size_t)k * res_stride + row * row_stride + i];
-            const uint32_t t = csub(redc_lazy((uint64_t)r * c.minv_m[k], c.q[k], c.nq[k]), c.q[k]);
-            const uint64_t lo = c.mi_lo[k] * t;
-            const uint64_t hi = __umul64hi(c.mi_lo[k], (uint64_t)t) + (uint64_t)c.mi_hi[k] * t;
-            s_lo += lo;
-            s_hi += hi + (s_lo < lo ? 1u : 0u);
+        for (int k = 0; k < 4; ++k) r[k] = res[(size_t)c.src[k] * res_stride + row * row_stride + i];
+        out[row * out_stride + i] = crt_merge_value(r, c);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_inv_strided_crt: the inverse column pass of all four CRT primes and the recombination in one kernel, so that the
+// residues never travel through HBM (the reference's merge loop, main_naive.cc:216-223, reads them back from four arrays).
+// A workgroup of 4 * CW threads takes CW adjacent columns of one product; its threads [k*CW, (k+1)*CW) run the column
+// pass of prime k (a whole number of wavefronts per prime, so the prime is uniform within a wavefront) and leave the
+// canonical residues of PH rows at a time in LDS; then every thread recombines PH/4 rows of its column and stores the
+// 64-bit coefficients.  src[k]: the core's output of prime k, rows of C << Q words; T3[k], fc[k]: that prime's tables.
+// ---------------------------------------------------------------------------
+struct CrtInvArgs {
+    const uint32_t* src[4];
+    const uint32_t* T3[4];
+    FieldConsts fc[4];
+};
+
+template <int Q, int CW, bool FULL>
+__global__ void __launch_bounds__(4 * CW) k_inv_strided_crt(CrtInvArgs a, uint64_t* out, size_t out_stride, int n_out, int C,
+                                                            CrtConsts c) {
+    constexpr int R = 1 << Q;
+    constexpr int PH = R < 16 ? R : 16;          // rows per exchange phase
+    static_assert(CW % 64 == 0 && PH % 4 == 0, "a prime owns whole wavefronts; every thread recombines PH / 4 rows");
+    __shared__ uint32_t xch[4][PH][CW];
+    const int k = NTT_UNIFORM((int)threadIdx.x / CW);
+    const int lane = (int)threadIdx.x % CW;
+    const int chunks = C / CW;
+    const int j = (int)(blockIdx.x % chunks) * CW + lane;
+    const size_t row = blockIdx.x / chunks;
+    uint32_t x[R];
+    // the second prime of the basis is the one above 2^30 (values kept fully reduced); the others run in the lazy ranges
+    if (k == 1) {
+        inv_column_regs<Q, false>(a.src[1] + row * ((size_t)C << Q), C, a.T3[1], a.fc[1], j, x);
+    } else {
+        const Field<true> f(a.fc[k]);
+        inv_column_regs<Q, true>(a.src[k] + row * ((size_t)C << Q), C, a.T3[k], a.fc[k], j, x);
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] = f.canon_inv(x[r]);
+    }
+    uint64_t* dst = out + row * out_stride;
+#pragma unroll
+    for (int ph = 0; ph < R / PH; ++ph) {
+        if (ph) __syncthreads();                  // the previous phase's residues have been read
+#pragma unroll
+        for (int i = 0; i < PH; ++i) xch[k][i][lane] = x[ph * PH + i];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < PH / 4; ++m) {
+            const int i = k * (PH / 4) + m;
+            const uint32_t r[4] = {xch[c.src[0]][i][lane], xch[c.src[1]][i][lane], xch[c.src[2]][i][lane], xch[c.src[3]][i][lane]};
+            const int idx = j + C * (ph * PH + i);
+            if ((FULL && ph * PH + i < R - 1) || idx < n_out) dst[idx] = crt_merge_value(r, c);
         }
-        // S < 4M: subtract 2M, then M, when possible
-        const uint64_t m2_lo = c.M_lo << 1, m2_hi = (c.M_hi << 1) | (c.M_lo >> 63);
-        if (s_hi > m2_hi || (s_hi == m2_hi && s_lo >= m2_lo)) {
-            const uint64_t b = s_lo < m2_lo ? 1u : 0u;
-            s_lo -= m2_lo; s_hi -= m2_hi + b;
-        }
-        if (s_hi > c.M_hi || (s_hi == c.M_hi && s_lo >= c.M_lo)) {
-            const uint64_t b = s_lo < c.M_lo ? 1u : 0u;
-            s_lo -= c.M_lo; s_hi -= c.M_hi + b;
-        }
-        const uint64_t r1 = rem_2by1(0, s_hi, c.d, c.v, c.shift);
-        out[row * out_stride + i] = rem_2by1(r1, s_lo, c.d, c.v, c.shift);
     }
 }
 

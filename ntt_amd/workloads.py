@@ -167,10 +167,10 @@ def large_modulus(torch, lib, clock, n=131072, p=BIG_P, batch=64, reps=20, polic
         lib.set_route_policy("auto")
     rate = batch / dt
     L = 1 << max(1, (2 * n - 2).bit_length())
-    crt = kernels.endswith("k_crt_merge")
-    moved = 336 * n if crt else 128 * n
-    note = ("per prime 72n (64-bit operand reads 16n -- the residue step rides on the first column pass --, its writes 16n, fused core 24n, "
-            "inverse column pass 16n) x 4 + merge 48n" if crt else
+    crt = "k_crt_merge" in kernels or "k_inv_strided_crt" in kernels
+    moved = 272 * n if crt else 128 * n
+    note = ("per prime 56n (64-bit operand reads 16n -- the residue step rides on the first column pass --, its writes 16n, fused core 24n) "
+            "x 4 + inverse column pass of the four primes with the merge in it 48n" if crt else
             "three transforms of one 64-bit array: operand passes 24n + 24n, fused core 48n, result pass 32n; the core is bound by vector issue")
     bfly = 3 * (L // 2) * (L.bit_length() - 1)
     issue = issue_bound(4 * bfly, rate, BUTTERFLIES32_PER_S) if crt else None

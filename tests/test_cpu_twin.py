@@ -42,6 +42,17 @@ def test_crt_path(twin, oracle, route):
     assert np.array_equal(twin.multiply_u64(a, a, BIGP), oracle.crt_ntt_multiply(a, a, BIGP))
 
 
+def test_crt_merge_against_python_integers(twin):
+    """the recombination kernel alone: Garner digits and both tails (exact doubles up to 1.5e15, 128-bit integers above)"""
+    import crt_merge_cases as cm
+    rng = np.random.default_rng(216)
+    xs = cm.cases(rng, 1500)
+    to_dev = lambda arr: {"arr": (a := np.ascontiguousarray(arr)), "ptr": a.ctypes.data}
+    from_dev = lambda d: d["arr"]
+    for p in cm.MODULI:
+        cm.check(twin, to_dev, from_dev, p, xs)
+
+
 @pytest.mark.parametrize("p,n", [(1000000007, 100), (97, 50), (2**31 - 1, 64), (4294967291, 16), (2**40 + 15, 300),
                                  (2**58 - 27, 4), (2, 10), (2**59 - 55, 1)])
 def test_arbitrary_moduli_through_crt(twin, oracle, p, n):
@@ -268,7 +279,7 @@ def test_route_selection_beyond_the_reference_range(twin):
         assert np.array_equal(got[5:5 + n], a) and not got[:5].any() and not got[5 + n:].any()
     assert twin.describe_plan(1 << 17, BIGP).startswith("k64_")
     assert twin.set_route_policy("reference") == "auto"
-    assert twin.describe_plan(1 << 17, BIGP).endswith("k_crt_merge")
+    assert twin.describe_plan(1 << 17, BIGP).endswith("k_inv_strided_crt")   # merge fused into the inverse column pass
     assert twin.describe_plan(1 << 18, BIGP).startswith("k64_")       # past the CRT route's length limit either way
     assert twin.set_route_policy("auto") == "reference"
     assert twin.lib.ntt_set_route_policy(7) == -1 and "route policy" in twin.last_error()

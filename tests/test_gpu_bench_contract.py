@@ -44,7 +44,7 @@ def test_bench_line_has_the_contract_keys():
     others = d["other_configs"]
     assert len(others) == 5 and all("error" not in o for o in others), others
     assert all(o["verified"] is True and o["poly_mults_per_s"] > 0 for o in others)
-    assert others[1]["kernels"].startswith("k64_") and others[2]["kernels"].endswith("k_crt_merge")
+    assert others[1]["kernels"].startswith("k64_") and others[2]["kernels"].endswith("k_inv_strided_crt")
     for o in others:     # every configuration prices itself against the HBM roofline, on the model's bytes and on the moved ones
         r = o["roofline"]
         assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1.0 and 0 < r["frac_moved"] < 1.0

@@ -268,3 +268,23 @@ def test_lifecycle_and_argument_errors(gpu_lib, oracle):
 def test_large_host_calls_go_through_in_chunks(gpu_lib, tmp_path):
     from test_cpu_twin import run_pipelined_worker
     run_pipelined_worker(gpu_lib.path, tmp_path)
+
+
+def test_crt_merge_against_python_integers(gpu_lib):
+    """the recombination kernel alone (main_naive.cc:216-223): Garner digits and both tails -- exact doubles for final moduli
+    up to 1.5e15, 128-bit integers above -- against Python integers, corners of the ranges included"""
+    import torch
+    import crt_merge_cases as cm
+    rng = np.random.default_rng(216)
+    xs = cm.cases(rng, 20000)
+
+    def to_dev(arr):
+        t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int32 if arr.dtype == np.uint32 else np.int64)).cuda()
+        return {"t": t, "ptr": t.data_ptr(), "dtype": arr.dtype}
+
+    def from_dev(d):
+        torch.cuda.synchronize()
+        return d["t"].cpu().numpy().view(d["dtype"])
+
+    for p in cm.MODULI:
+        cm.check(gpu_lib, to_dev, from_dev, p, xs)

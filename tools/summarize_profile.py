@@ -54,6 +54,16 @@ def main(src, tag, batch=256, n=131072):
                          "avg_us_after_60ms": sum(late) / len(late) / 1e3 if late else None,
                          "launches_after_60ms": len(late)}
         json.dump(steady, open(os.path.join(dst, f"{tag}_clock_transient.json"), "w"), indent=1, sort_keys=True)
+        # the same summary as rocprofv3's kernel_stats, over the launches that start 60 ms or more after the first one only
+        # (the steady state: the clock transient of the first ~25 ms is left out)
+        with open(os.path.join(dst, f"{tag}_kernel_stats_steady.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Note"])
+            for k, v in sorted(per.items()):
+                late = [d for s_, d in v if s_ - t0 >= 60e6]
+                if late:
+                    w.writerow([k, len(late), sum(late), sum(late) / len(late), min(late), max(late),
+                                "launches starting >= 60 ms after the first launch of the trace"])
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
     for path in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(path)):
