@@ -354,41 +354,57 @@ void launch_multipass(const Plan& pl, const TIn* a, const TIn* b, TOut* out, int
     else launch_multipass_v<Q, LZ, false, MINW>(pl, a, b, out, n, batch, sa, sb, so, tmpA, tmpB, st);
 }
 
-// The four-prime route with the recombination fused into the inverse column pass (transform lengths 2^14 .. 2^18): per
-// prime the forward column passes and the core, its result left in that prime's plane; then one launch runs the inverse
-// column pass of all four primes and merges in LDS.
+// The four-prime route at transform lengths 2^14 .. 2^18: one launch reduces the operands modulo the four primes and runs
+// their forward column passes (the operands are read once), the fused core runs once per prime, and one launch runs the
+// inverse column pass of all four primes and merges in LDS (the residues never reach HBM).
 #ifndef NTT_CRT_INV_CW
 #define NTT_CRT_INV_CW 64
 #endif
-constexpr int CRT_INV_CW = NTT_CRT_INV_CW;   // columns per workgroup of k_inv_strided_crt (4 * CW threads)
+#ifndef NTT_CRT_FWD_CW
+#define NTT_CRT_FWD_CW 64
+#endif
+constexpr int CRT_FWD_CW = NTT_CRT_FWD_CW;
+constexpr int CRT_INV_CW = NTT_CRT_INV_CW;   // columns per workgroup of the four-prime column passes (4 * CW threads)
 
 template <int Q>
 void launch_crt_multipass(Plan* const (&pl)[4], const uint64_t* a, const uint64_t* b, uint64_t* out, int n, size_t batch, size_t sa,
-                          size_t sb, size_t so, uint32_t* planes, size_t plane_stride, uint32_t* tmpB, const CrtConsts& c,
-                          hipStream_t st) {
+                          size_t sb, size_t so, uint32_t* planes, size_t plane_stride, const CrtConsts& c, hipStream_t st) {
     const bool full = (2 * (size_t)n == ((size_t)CORE_N << Q));
     constexpr int MINW = multipass_minw(Q);
-    CrtInvArgs args;
+    constexpr int CW = CRT_INV_CW;
+    // planes: A of the four primes, then B of the four primes
+    CrtFwdArgs fa;
+    CrtInvArgs ia;
     for (int i = 0; i < 4; ++i) {
-        uint32_t* tmpA = planes + i * plane_stride;
-        if (pl[i]->h.lazy) {
-            if (full) launch_fwd_core_v<Q, true, true, MINW>(*pl[i], a, b, n, batch, sa, sb, tmpA, tmpB, st);
-            else launch_fwd_core_v<Q, true, false, MINW>(*pl[i], a, b, n, batch, sa, sb, tmpA, tmpB, st);
-        } else {
-            if (full) launch_fwd_core_v<Q, false, true, MINW>(*pl[i], a, b, n, batch, sa, sb, tmpA, tmpB, st);
-            else launch_fwd_core_v<Q, false, false, MINW>(*pl[i], a, b, n, batch, sa, sb, tmpA, tmpB, st);
-        }
-        args.src[i] = tmpA;
-        args.T3[i] = pl[i]->T3;
-        args.fc[i] = pl[i]->h.fc;
+        fa.T1[i] = pl[i]->T1;
+        fa.outA[i] = planes + i * plane_stride;
+        fa.outB[i] = planes + (4 + i) * plane_stride;
+        fa.fc[i] = pl[i]->h.fc;
+        ia.src[i] = fa.outA[i];
+        ia.T3[i] = pl[i]->T3;
+        ia.fc[i] = pl[i]->h.fc;
     }
-    const unsigned grid = (unsigned)((CORE_N / CRT_INV_CW) * batch);
+    const unsigned grid = (unsigned)((CORE_N / CW) * batch);
+    constexpr int FW = CRT_FWD_CW;
+    const unsigned fgrid = (unsigned)((CORE_N / FW) * batch);
     if (full)
-        NTT_LAUNCH_P("k_inv_strided_crt", (k_inv_strided_crt<Q, CRT_INV_CW, true>), dim3(grid), dim3(4 * CRT_INV_CW), st, args, out, so,
-                     2 * n - 1, CORE_N, c);
+        NTT_LAUNCH_P("k_fwd_strided_crt", (k_fwd_strided_crt<Q, FW, true, MINW>), dim3(fgrid, 1, 2), dim3(4 * FW), st, a, b, sa, sb, n,
+                     CORE_N, fa);
     else
-        NTT_LAUNCH_P("k_inv_strided_crt", (k_inv_strided_crt<Q, CRT_INV_CW, false>), dim3(grid), dim3(4 * CRT_INV_CW), st, args, out, so,
-                     2 * n - 1, CORE_N, c);
+        NTT_LAUNCH_P("k_fwd_strided_crt", (k_fwd_strided_crt<Q, FW, false, MINW>), dim3(fgrid, 1, 2), dim3(4 * FW), st, a, b, sa, sb, n,
+                     CORE_N, fa);
+    for (int i = 0; i < 4; ++i) {
+        if (pl[i]->h.lazy)
+            NTT_LAUNCH_P("k_core_mul", (k_core_mul<true>), dim3((unsigned)(batch << Q)), dim3(CORE_T), st, (const uint32_t*)fa.outA[i],
+                         (const uint32_t*)fa.outB[i], fa.outA[i], pl[i]->h.fc, pl[i]->core);
+        else
+            NTT_LAUNCH_P("k_core_mul", (k_core_mul<false>), dim3((unsigned)(batch << Q)), dim3(CORE_T), st, (const uint32_t*)fa.outA[i],
+                         (const uint32_t*)fa.outB[i], fa.outA[i], pl[i]->h.fc, pl[i]->core);
+    }
+    if (full)
+        NTT_LAUNCH_P("k_inv_strided_crt", (k_inv_strided_crt<Q, CW, true>), dim3(grid), dim3(4 * CW), st, ia, out, so, 2 * n - 1, CORE_N, c);
+    else
+        NTT_LAUNCH_P("k_inv_strided_crt", (k_inv_strided_crt<Q, CW, false>), dim3(grid), dim3(4 * CW), st, ia, out, so, 2 * n - 1, CORE_N, c);
 }
 
 template <bool LZ, typename TIn, typename TOut>
@@ -508,6 +524,9 @@ bool crt_fused_merge_allowed() {
 
 size_t crt_workspace_bytes(int logL, size_t batch) {
     const size_t L = (size_t)1 << logL;
+    // multi-pass lengths: the column-pass results of both operands for the four primes (eight planes); shorter ones: the
+    // four residue planes
+    if (logL >= 14) return 8 * batch * L * sizeof(uint32_t);
     return pipeline_workspace_bytes(logL, batch) + 4 * batch * L * sizeof(uint32_t);
 }
 
@@ -532,8 +551,8 @@ int crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, uint64
     CrtConsts c;
     int rc = make_crt_consts(p, &c);
     if (rc != NTT_OK) return rc;
-    // multi-pass lengths: the merge rides on the inverse column pass.  The basis is fixed: its second prime is the one
-    // kept fully reduced, the kernel relies on that
+    // multi-pass lengths: the residue step rides on one forward column pass for all four primes and the merge on the
+    // inverse one.  The basis is fixed: its second prime is the one kept fully reduced, the kernels rely on that
     Plan* pl[4];
     bool multipass = true;
     for (int i = 0; i < 4; ++i) {
@@ -541,14 +560,13 @@ int crt_product_device(Device* dev, const uint64_t* a, const uint64_t* b, uint64
         multipass = multipass && pl[i]->h.kind == PLAN_MULTIPASS && pl[i]->h.lazy == (i != 1);
     }
     if (multipass && crt_fused_merge_allowed()) {
-        // workspace: [tmpB | unused half of the pipeline area][four planes]; a prime's own plane takes the place of tmpA
-        uint32_t* tmpB = (uint32_t*)ws;
+        uint32_t* planes = (uint32_t*)ws;
         switch (pl[0]->h.Q) {
-            case 2: launch_crt_multipass<2>(pl, a, b, out, n, batch, sa, sb, so, res, res_stride, tmpB, c, st); break;
-            case 3: launch_crt_multipass<3>(pl, a, b, out, n, batch, sa, sb, so, res, res_stride, tmpB, c, st); break;
-            case 4: launch_crt_multipass<4>(pl, a, b, out, n, batch, sa, sb, so, res, res_stride, tmpB, c, st); break;
-            case 5: launch_crt_multipass<5>(pl, a, b, out, n, batch, sa, sb, so, res, res_stride, tmpB, c, st); break;
-            case 6: launch_crt_multipass<6>(pl, a, b, out, n, batch, sa, sb, so, res, res_stride, tmpB, c, st); break;
+            case 2: launch_crt_multipass<2>(pl, a, b, out, n, batch, sa, sb, so, planes, res_stride, c, st); break;
+            case 3: launch_crt_multipass<3>(pl, a, b, out, n, batch, sa, sb, so, planes, res_stride, c, st); break;
+            case 4: launch_crt_multipass<4>(pl, a, b, out, n, batch, sa, sb, so, planes, res_stride, c, st); break;
+            case 5: launch_crt_multipass<5>(pl, a, b, out, n, batch, sa, sb, so, planes, res_stride, c, st); break;
+            case 6: launch_crt_multipass<6>(pl, a, b, out, n, batch, sa, sb, so, planes, res_stride, c, st); break;
             default: return fail(NTT_ERR_ARG, "unsupported strided radix");
         }
         HIP_TRY(hipGetLastError());
@@ -2274,7 +2292,7 @@ int ntt_describe_plan(int n, uint64_t p, char* buf, size_t buf_len) {
     const char* pipe = logL <= 12 ? ((logL >= 5 && p < (1ull << 31) && (p - 1) % 64 == 0) ? "k_small16" : "k_small") : logL == 13 ? "k_fused8192" : "k_fwd_strided,k_core_mul,k_inv_strided";
     if (route == ROUTE_DIRECT32) s = pipe;
     else if (route == ROUTE_CRT)
-        s = (logL >= 14 && crt_fused_merge_allowed()) ? std::string("4x(k_fwd_strided,k_core_mul),k_inv_strided_crt")
+        s = (logL >= 14 && crt_fused_merge_allowed()) ? std::string("k_fwd_strided_crt,4x(k_core_mul),k_inv_strided_crt")
                                                       : std::string("4x(") + pipe + "),k_crt_merge";
     else if (route == ROUTE_FIELD64 || route == ROUTE_WIDECRT) {
         // the launches of one product in the 64-bit field, in order of first use

@@ -224,9 +224,9 @@ __global__ void __launch_bounds__(CORE_T) k_core_mul(const uint32_t* tmpA, const
 // * w_Lb^(j*bitrev_Q(pos)).  Twiddle table layout: [(pos>>2)][j][pos&3], so a thread's 4
 // consecutive positions are one 16-byte load and neighbouring threads are contiguous.
 // ---------------------------------------------------------------------------
-template <int Q, bool LZ, bool PADDED, bool FULL, typename TIn>
-__device__ __forceinline__ void fwd_column(const TIn* src, int n_valid, uint32_t* dst, int C, const uint32_t* T1,
-                                           const FieldConsts& fc, int j) {
+// load(r, f): the reduced coefficient of row r of this column (rows below R/2 only when PADDED)
+template <int Q, bool LZ, bool PADDED, class Load>
+__device__ __forceinline__ void fwd_column_from(Load&& load, uint32_t* dst, int C, const uint32_t* T1, const FieldConsts& fc, int j) {
     constexpr int R = 1 << Q;
     const Field<LZ> f(fc);
     uint32_t x[R];
@@ -236,10 +236,7 @@ __device__ __forceinline__ void fwd_column(const TIn* src, int n_valid, uint32_t
     const uint4* Tq = reinterpret_cast<const uint4*>(T1) + j;
     uint4 wb[2][SG];
 #pragma unroll
-    for (int r = 0; r < (PADDED ? R / 2 : R); ++r) {
-        const int idx = j + C * r;
-        x[r] = (!PADDED || FULL) ? load_coeff<LZ>(src, (size_t)idx, f, fc) : load_coeff_padded<LZ>(src, idx, n_valid, f, fc);
-    }
+    for (int r = 0; r < (PADDED ? R / 2 : R); ++r) x[r] = load(r, f);
 #pragma unroll
     for (int k = 0; k < SG; ++k) wb[0][k] = Tq[(size_t)k * C];
     NTT_FENCE();
@@ -272,6 +269,15 @@ __device__ __forceinline__ void fwd_column(const TIn* src, int n_valid, uint32_t
         }
         NTT_FENCE();
     }
+}
+
+template <int Q, bool LZ, bool PADDED, bool FULL, typename TIn>
+__device__ __forceinline__ void fwd_column(const TIn* src, int n_valid, uint32_t* dst, int C, const uint32_t* T1,
+                                           const FieldConsts& fc, int j) {
+    fwd_column_from<Q, LZ, PADDED>([&](int r, const Field<LZ>& f) {
+        const int idx = j + C * r;
+        return (!PADDED || FULL) ? load_coeff<LZ>(src, (size_t)idx, f, fc) : load_coeff_padded<LZ>(src, idx, n_valid, f, fc);
+    }, dst, C, T1, fc, j);
 }
 
 // inv_column_regs: mirror of fwd_column up to the registers: x[r] = value of row r of column j after the twiddles and the
@@ -678,6 +684,52 @@ __global__ void __launch_bounds__(256) k_crt_merge(const uint32_t* res, size_t r
 // canonical residues of PH rows at a time in LDS; then every thread recombines PH/4 rows of its column and stores the
 // 64-bit coefficients.  src[k]: the core's output of prime k, rows of C << Q words; T3[k], fc[k]: that prime's tables.
 // ---------------------------------------------------------------------------
+// k_fwd_strided_crt: the forward column pass of all four CRT primes in one launch.  A workgroup of 4 * CW threads takes
+// CW adjacent columns of one operand row; its threads [k*CW, (k+1)*CW) reduce the 64-bit coefficients modulo prime k
+// (the reference's residue step, main_naive.cc:206-209) and run that prime's column pass.  The workgroup brings the operand
+// words of its columns into LDS once; every prime's group reads them from there.
+struct CrtFwdArgs {
+    const uint32_t* T1[4];
+    uint32_t* outA[4];
+    uint32_t* outB[4];
+    FieldConsts fc[4];
+};
+
+template <int Q, int CW, bool FULL, int MINW>
+__global__ void __launch_bounds__(4 * CW, MINW) k_fwd_strided_crt(const uint64_t* inA, const uint64_t* inB, size_t a_stride,
+                                                                  size_t b_stride, int n_valid, int C, CrtFwdArgs a) {
+    static_assert(CW % 64 == 0, "a prime owns whole wavefronts");
+    constexpr int R = 1 << Q, RH = R / 2;       // rows of the column, rows that hold coefficients (the rest is padding)
+    __shared__ uint64_t raw[RH][CW];
+    const int k = NTT_UNIFORM((int)threadIdx.x / CW);
+    const int lane = (int)threadIdx.x % CW;
+    const int chunks = C / CW;
+    const int j0 = (int)(blockIdx.x % chunks) * CW;
+    const size_t row = blockIdx.x / chunks;
+    const uint64_t* src = blockIdx.z ? inB + row * b_stride : inA + row * a_stride;
+    uint32_t* dst = (blockIdx.z ? a.outB[k] : a.outA[k]) + row * ((size_t)C << Q);
+    // the operand words of these columns, once for the four primes (zero beyond the operand's length)
+#pragma unroll
+    for (int e = (int)threadIdx.x; e < RH * CW; e += 4 * CW) {
+        const int r = e / CW, col = e % CW;
+        const int idx = j0 + col + C * r;
+        const bool inside = FULL || idx < n_valid;
+        const uint64_t v = src[inside ? idx : 0];
+        raw[r][col] = inside ? v : 0;
+    }
+    __syncthreads();
+    // the second prime of the basis is the one above 2^30 (values kept fully reduced); the others run in the lazy ranges
+    if (k == 1) {
+        const FieldConsts& fc = a.fc[1];
+        fwd_column_from<Q, false, true>([&](int r, const Field<false>& f) { return f.reduce64(raw[r][lane], fc.r1, fc.r2); },
+                                        dst, C, a.T1[1], fc, j0 + lane);
+    } else {
+        const FieldConsts& fc = a.fc[k];
+        fwd_column_from<Q, true, true>([&](int r, const Field<true>& f) { return f.reduce64(raw[r][lane], fc.r1, fc.r2); },
+                                       dst, C, a.T1[k], fc, j0 + lane);
+    }
+}
+
 struct CrtInvArgs {
     const uint32_t* src[4];
     const uint32_t* T3[4];

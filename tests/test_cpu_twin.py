@@ -100,7 +100,7 @@ def test_error_reporting(twin):
     assert twin.describe_plan(4096, 998244353) == "k_fused8192"
     twin.set_route_policy("reference")
     assert twin.describe_plan(4, BIGP).endswith("k_crt_merge")
-    assert twin.lib.ntt_workspace_bytes(131072, BIGP, 3) == 2 * 3 * (1 << 18) * 4 + 4 * 3 * (1 << 18) * 4
+    assert twin.lib.ntt_workspace_bytes(131072, BIGP, 3) == 8 * 3 * (1 << 18) * 4    # both operands x four primes
     twin.set_route_policy("auto")
     assert twin.describe_plan(4, BIGP).startswith("k64_")
     assert twin.lib.ntt_workspace_bytes(1024, BIGP, 3) == twin.lib.ntt64_workspace_bytes_batched(1024, 3) == 2 * 3 * 2048 * 8
