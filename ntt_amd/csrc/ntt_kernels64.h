@@ -247,10 +247,24 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
                 const uint64_t dstep = (uint64_t)sub * step;
                 const uint64_t* src_row = SRC_RAW ? src + blk_g * g.src_stride : nullptr;   // uniform over the workgroup
                 uint64_t pos = col + (uint64_t)row0 * step;                                   // offset inside the block
+                if (SRC_RAW) {
+                    // The address is always a valid one and the zero is selected afterwards: a conditional load is compiled
+                    // as a branch per element, which ends the basic block and makes every load wait for the one before it.
+                    uint64_t word[16];
+                    bool inside[16];
 #pragma unroll
-                for (int m = 0; m < 16; ++m, idx += dstep, pos += dstep) {
-                    if (SRC_RAW) v[m] = pos < g.src_valid ? f.from_raw(src_row[pos]) : V(0);
-                    else v[m] = f.from_mem(data[idx]);
+                    for (int m = 0; m < 16; ++m, pos += dstep) {
+                        inside[m] = pos < g.src_valid;
+                        word[m] = src_row[inside[m] ? pos : 0];
+                    }
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) {
+                        const V r = f.from_raw(word[m]);
+                        v[m] = inside[m] ? r : V(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 16; ++m, idx += dstep) v[m] = f.from_mem(data[idx]);
                 }
             } else {
 #pragma unroll
@@ -638,30 +652,47 @@ __global__ void __launch_bounds__(256) k64_strided(uint64_t* data, const uint64_
     uint64_t* base = data + origin;
     const uint64_t step = g.step;
     V x[16];
+    // Everything this thread reads -- its column and the table words of its twiddles -- is requested before anything is
+    // used, and nothing is read conditionally (a conditional load is compiled as a branch, which ends the basic block and
+    // makes every load wait for the one before it): an operand row's padding is replaced by zero after the load, and a
+    // twiddle with exponent zero is looked up like any other (both table words are then the constant one).
+    if (SRC_RAW) {
+        uint64_t word[R];
+        bool inside[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (SRC_RAW) {
+        for (int r = 0; r < R; ++r) {
             const uint64_t pos = col + (uint64_t)r * step;
-            x[r] = pos < g.src_valid ? f.from_raw(src[blk * g.src_stride + pos]) : V(0);
-        } else {
-            x[r] = f.from_mem(base[(uint64_t)r * step]);
+            inside[r] = pos < g.src_valid;
+            word[r] = src[blk * g.src_stride + (inside[r] ? pos : 0)];
         }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const V v = f.from_raw(word[r]);
+            x[r] = inside[r] ? v : V(0);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) x[r] = f.from_mem(base[(uint64_t)r * step]);
     }
+    uint64_t t1[R], t0[R];
+    {
+        const uint64_t lo_mask = ((uint64_t)1 << tw.t0) - 1;
+        static_for<1, R>([&](auto P) {
+            constexpr int pos = decltype(P)::value;
+            constexpr int k = bitrev(pos, Q);
+            uint64_t e = jq * (uint64_t)k * g.tw_stride;
+            if (INVERSE) e = 0 - e;
+            e &= g.tw_mask;
+            t1[pos] = tw.w1[e >> tw.t0];
+            t0[pos] = tw.w0[e & lo_mask];
+        });
+    }
+    auto pass_twiddle = [&](int pos) -> W { return f.twmul(f.tw_from_mem(t1[pos]), f.tw_from_mem(t0[pos])); };
     if (!INVERSE) {
         dif_sub<F, Q, 0>(x, f, rF);
-        static_for<1, R>([&](auto P) {
-            constexpr int pos = decltype(P)::value;
-            constexpr int k = bitrev(pos, Q);
-            const uint64_t e = (jq * (uint64_t)k * g.tw_stride) & g.tw_mask;
-            if (e != 0) x[pos] = f.twiddled(x[pos], twiddle_pow(tw, f, e));
-        });
+        static_for<1, R>([&](auto P) { constexpr int pos = decltype(P)::value; x[pos] = f.twiddled(x[pos], pass_twiddle(pos)); });
     } else {
-        static_for<1, R>([&](auto P) {
-            constexpr int pos = decltype(P)::value;
-            constexpr int k = bitrev(pos, Q);
-            const uint64_t e = (0 - jq * (uint64_t)k * g.tw_stride) & g.tw_mask;  // negative exponent
-            if (e != 0) x[pos] = f.twiddled(x[pos], twiddle_pow(tw, f, e));
-        });
+        static_for<1, R>([&](auto P) { constexpr int pos = decltype(P)::value; x[pos] = f.twiddled(x[pos], pass_twiddle(pos)); });
         dit_sub<F, Q, 0>(x, f, rI);
     }
 #pragma unroll

@@ -127,3 +127,14 @@ def test_one_product_of_2_pow_28_coefficients(gpu_lib):
     rng = np.random.default_rng(2028)
     for x in (1, p - 1, int(rng.integers(2, p - 1)), int(rng.integers(2, p - 1))):
         assert evaluate(a, x, p) * evaluate(b, x, p) % p == evaluate(out, x, p), x
+    # 4. the same product in its explicit four-step form -- the matrix passes the multi-rank run uses
+    #    (ntt64_fourstep_rows_load / cols_product / rows_store; replaces main_mpi_t.cc:139-291), here with one rank holding
+    #    the whole matrix -- must equal the direct product bit for bit
+    from ntt_amd.fourstep import FourStep
+    fs = FourStep(gpu_lib, p, n, torch.device("cuda", torch.cuda.current_device()))
+    assert fs.world == 1 and fs.R * fs.C == 2 * n
+    sa, sb = fs.column_slab_device(a), fs.column_slab_device(b)
+    c = fs.multiply_slabs(sa, sb)
+    torch.cuda.synchronize()
+    assert torch.equal(c.reshape(-1)[:n_out], out)
+
