@@ -185,7 +185,7 @@ NTT_HD uint64_t bitrev64(uint64_t x, int bits) {
 //   every row to `out` instead of `data`.
 // ---------------------------------------------------------------------------
 template <class F, bool INVERSE, bool SRC_RAW, bool FINAL>
-__global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint64_t* src, uint64_t* out, uint64_t n_out,
+__global__ void __launch_bounds__(TILE64_T, 4) k64_tile(uint64_t* data, const uint64_t* src, uint64_t* out, uint64_t n_out,
                                                      typename F::W scale, Pass64 g, typename F::Consts fc, Twiddle64 tw,
                                                      RoundTables64 rt) {
     typedef typename F::V V;
@@ -217,72 +217,95 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
     // e0 + bitrev4(i) * de with two per-thread constants.  Only w^e0 and w^de are looked up (lanes hold different
     // columns, so every lookup is a gather over the table); the sixteen twiddles w^(e0 + c*de) are then built by
     // multiplication: three squarings of w^de and one multiply per twiddle.
+    // Memory requests go out as early as possible and in batches: the thread's sixteen data words first, then the four table
+    // words of the pass twiddles and the round twiddles of the first round; the chain of multiplications that builds the
+    // pass twiddles runs while the data is on its way, and every later round asks for its twiddle row before the barrier
+    // in front of it.  Compiler-only fences pin that order.
     W ptw[16];   // indexed by c = bitrev4(i)
-    {
+    uint64_t ptw_word[4];
+    auto request_pass_twiddles = [&]() {
         const uint64_t k0 = bitrev64((uint64_t)grp, q - 4);
         uint64_t e0 = (jq * k0 * g.tw_stride) & g.tw_mask, de = ((jq << (q - 4)) * g.tw_stride) & g.tw_mask;
         if (INVERSE) { e0 = (0 - e0) & g.tw_mask; de = (0 - de) & g.tw_mask; }
         const uint64_t lo_mask = ((uint64_t)1 << tw.t0) - 1;
-        auto lookup = [&](uint64_t e) -> W {
-            return f.twmul(f.tw_from_mem(tw.w1[e >> tw.t0]), f.tw_from_mem(tw.w0[e & lo_mask]));
-        };
-        const W s1 = lookup(de), s2 = f.twmul(s1, s1), s4 = f.twmul(s2, s2), s8 = f.twmul(s4, s4);
-        ptw[0] = lookup(e0);
+        ptw_word[0] = tw.w1[de >> tw.t0]; ptw_word[1] = tw.w0[de & lo_mask];
+        ptw_word[2] = tw.w1[e0 >> tw.t0]; ptw_word[3] = tw.w0[e0 & lo_mask];
+    };
+    auto build_pass_twiddles = [&]() {
+        const W s1 = f.twmul(f.tw_from_mem(ptw_word[0]), f.tw_from_mem(ptw_word[1]));
+        const W s2 = f.twmul(s1, s1), s4 = f.twmul(s2, s2), s8 = f.twmul(s4, s4);
+        ptw[0] = f.twmul(f.tw_from_mem(ptw_word[2]), f.tw_from_mem(ptw_word[3]));
         static_for<1, 16>([&](auto C) {
             constexpr int c = decltype(C)::value;
             constexpr int low = c & -c;                       // lowest set bit: ptw[c] = ptw[c - low] * w^(low * de)
             ptw[c] = f.twmul(ptw[c - low], low == 1 ? s1 : low == 2 ? s2 : low == 4 ? s4 : s8);
         });
-    }
+    };
     auto pass_twiddle = [&](auto I) -> W { return ptw[bitrev(decltype(I)::value, 4)]; };
+    uint64_t rtw[16];   // round twiddles of the coming round (table words)
+    auto request_round_twiddles = [&](const uint64_t* table, int j) {
+        const uint64_t* T = table + ((size_t)j << 4);
+#pragma unroll
+        for (int pos = 1; pos < 16; ++pos) rtw[pos] = T[pos];
+    };
 
     if (!INVERSE) {
-        bool first = true;
+        uint64_t word[16];
+        bool inside[16];
+        if (q > 4) {      // first round reads memory: rows row0 + m * sub
+            const int b = q, sub = 1 << (b - 4);
+            const int blk = grp >> (b - 4), j = grp & (sub - 1);
+            const int row0 = (blk << b) + j;
+            uint64_t idx = origin + (uint64_t)row0 * step;
+            const uint64_t dstep = (uint64_t)sub * step;
+            const uint64_t* src_row = SRC_RAW ? src + blk_g * g.src_stride : nullptr;   // uniform over the workgroup
+            uint64_t pos = col + (uint64_t)row0 * step;                                   // offset inside the block
+            if (SRC_RAW) {
+                // The address is always a valid one and the zero is selected afterwards: a conditional load is compiled
+                // as a branch per element, which ends the basic block and makes every load wait for the one before it.
+#pragma unroll
+                for (int m = 0; m < 16; ++m, pos += dstep) {
+                    inside[m] = pos < g.src_valid;
+                    word[m] = src_row[inside[m] ? pos : 0];
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 16; ++m, idx += dstep) word[m] = data[idx];
+            }
+            request_pass_twiddles();      // used after the last round only: the table words wait in eight registers, the
+            request_round_twiddles(rt.f[b], j);   // sixteen twiddles are built there
+            NTT_FENCE64();
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (SRC_RAW) { const V r = f.from_raw(word[m]); v[m] = inside[m] ? r : V(0); }
+                else v[m] = f.from_mem(word[m]);
+            }
+        }
         for (int b = q; b > 4; b -= 4) {         // rounds over blocks of 2^b rows
             const int sub = 1 << (b - 4);
             const int blk = grp >> (b - 4), j = grp & (sub - 1);
             const int row0 = (blk << b) + j;
-            if (first) {
-                uint64_t idx = origin + (uint64_t)row0 * step;
-                const uint64_t dstep = (uint64_t)sub * step;
-                const uint64_t* src_row = SRC_RAW ? src + blk_g * g.src_stride : nullptr;   // uniform over the workgroup
-                uint64_t pos = col + (uint64_t)row0 * step;                                   // offset inside the block
-                if (SRC_RAW) {
-                    // The address is always a valid one and the zero is selected afterwards: a conditional load is compiled
-                    // as a branch per element, which ends the basic block and makes every load wait for the one before it.
-                    uint64_t word[16];
-                    bool inside[16];
-#pragma unroll
-                    for (int m = 0; m < 16; ++m, pos += dstep) {
-                        inside[m] = pos < g.src_valid;
-                        word[m] = src_row[inside[m] ? pos : 0];
-                    }
-#pragma unroll
-                    for (int m = 0; m < 16; ++m) {
-                        const V r = f.from_raw(word[m]);
-                        v[m] = inside[m] ? r : V(0);
-                    }
-                } else {
-#pragma unroll
-                    for (int m = 0; m < 16; ++m, idx += dstep) v[m] = f.from_mem(data[idx]);
-                }
-            } else {
+            if (b < q) {
 #pragma unroll
                 for (int m = 0; m < 16; ++m) v[m] = lds[tile_slot(row0 + m * sub)];
             }
             NTT_MATH64(dif_blocks<F, 4, true>(v, f, rF); v[0] = f.settle(v[0]));
-            const uint64_t* T = rt.f[b] + ((size_t)j << 4);
 #pragma unroll
-            for (int pos = 1; pos < 16; ++pos) NTT_MATH64(v[pos] = f.twiddled(v[pos], f.tw_from_mem(T[pos])));
+            for (int pos = 1; pos < 16; ++pos) NTT_MATH64(v[pos] = f.twiddled(v[pos], f.tw_from_mem(rtw[pos])));
 #pragma unroll
             for (int m = 0; m < 16; ++m) lds[tile_slot(row0 + m * sub)] = v[m];
+            if (b - 4 > 4) {                     // the next round's twiddle row travels while the workgroup synchronises
+                NTT_FENCE64();
+                request_round_twiddles(rt.f[b - 4], grp & ((1 << (b - 8)) - 1));
+                NTT_FENCE64();
+            }
             __syncthreads();
-            first = false;
         }
         // last round: rows 16*grp + i, blocks of 2^ql rows; then the pass twiddle and the store
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = lds[tile_slot((grp << 4) + i)];
         NTT_MATH64(dif_blocks_rt<F>(ql, v, f, rF));
+        build_pass_twiddles();
         uint64_t idx = origin + (uint64_t)(grp << 4) * step;
         static_for<0, 16>([&](auto I) {
             constexpr int i = decltype(I)::value;
@@ -292,8 +315,16 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
     } else {
         // first round of the inverse = mirror of the last forward round
         uint64_t idx = origin + (uint64_t)(grp << 4) * step;
+        uint64_t word[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i, idx += step) v[i] = f.from_mem(data[idx]);
+        for (int i = 0; i < 16; ++i, idx += step) word[i] = data[idx];
+        request_pass_twiddles();
+        if (ql + 4 <= q) request_round_twiddles(rt.i[ql + 4], grp & ((1 << ql) - 1));
+        NTT_FENCE64();
+        build_pass_twiddles();
+        NTT_FENCE64();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = f.from_mem(word[i]);
         static_for<0, 16>([&](auto I) { constexpr int i = decltype(I)::value; NTT_MATH64(v[i] = f.twiddled(v[i], pass_twiddle(I))); });
         NTT_MATH64(dit_blocks_rt<F, true>(ql, v, f, rI));
 #pragma unroll
@@ -303,17 +334,19 @@ __global__ void __launch_bounds__(TILE64_T) k64_tile(uint64_t* data, const uint6
             const int sub = 1 << (b - 4);
             const int blk = grp >> (b - 4), j = grp & (sub - 1);
             const int row0 = (blk << b) + j;
-            const uint64_t* T = rt.i[b] + ((size_t)j << 4);
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 const V r = lds[tile_slot(row0 + m * sub)];
                 v[m] = r;
-                NTT_MATH64(v[m] = m ? f.twiddled(r, f.tw_from_mem(T[m])) : f.settle(r));
+                NTT_MATH64(v[m] = m ? f.twiddled(r, f.tw_from_mem(rtw[m])) : f.settle(r));
             }
             NTT_MATH64(dit_blocks<F, 4, true>(v, f, rI));
             if (b < q) {
 #pragma unroll
                 for (int m = 0; m < 16; ++m) lds[tile_slot(row0 + m * sub)] = v[m];
+                NTT_FENCE64();
+                request_round_twiddles(rt.i[b + 4], grp & ((1 << b) - 1));
+                NTT_FENCE64();
                 __syncthreads();
             } else {
                 uint64_t o = origin + (uint64_t)row0 * step;
