@@ -600,6 +600,8 @@ __global__ void __launch_bounds__(LOCAL64_T, F::SHORT_MUL_WAVES) k64_short_mul(c
                 int e = t + LOCAL64_T * i;
                 NTT_OPAQUE(e);
                 const uint64_t row = row0 + ((uint64_t)e >> m), pos = (uint64_t)e & pos_mask;
+                // (conditional loads, i.e. a branch per element: measured 8-10 % faster here than loading unconditionally and
+                // selecting the zero afterwards -- this kernel is bound by vector issue, not by the latency of its loads)
                 lds[local_slot(e)] = (row < rows && pos < n) ? f.from_raw(src[row * stride + pos]) : V(0);
             }
             __syncthreads();
