@@ -216,6 +216,11 @@ int ntt64_poly_multiply_batched_device(const uint64_t *d_a, const uint64_t *d_b,
  * mod p on the way in and canonical on the way out.  Host form (one row) and device form (batch rows). */
 int ntt_transform_u64(uint64_t *a, int n, int invert, uint64_t p);
 int ntt_transform_device_u64(uint64_t *d_a, size_t n, size_t batch, int invert, uint64_t p, void *stream);
+/* The same transform on 32-bit residues (p < 2^31, n = 2 .. 2^18 with n | p-1, values in [0, p)), in place on batch rows
+ * of n values: three passes of 8 bytes per value through a library-owned work array of the same size (none for
+ * n <= 4096).  The two entry points above take this route too whenever the modulus allows it, with 8-byte words at the
+ * two ends only. */
+int ntt_transform_device_u32(uint32_t *d_a, size_t n, size_t batch, int invert, uint32_t p, void *stream);
 
 /* Data files of the reference harness, host-only (no GPU needed): `<id>.in` = "n p", n coefficients of a,
  * n of b, white-space separated (fRead, main_naive.cc:13-30); `<id>.out` = 2n-1 values, one per line

@@ -29,7 +29,7 @@ EXPORTS = [
     "ntt64_fourstep_rows_load_device", "ntt64_fourstep_rows_store_device", "ntt64_fourstep_cols_product_device", "ntt64_twiddle_device", "ntt64_pointwise_device", "ntt64_load_device",
     "ntt64_finalize_device", "ntt64_workspace_bytes", "ntt64_poly_multiply_device",
     "ntt64_workspace_bytes_batched", "ntt64_poly_multiply_batched_device",
-    "ntt_transform_u64", "ntt_transform_device_u64",
+    "ntt_transform_u64", "ntt_transform_device_u64", "ntt_transform_device_u32",
     "ntt_io_read_header", "ntt_io_read_in", "ntt_io_check_out", "ntt_io_read_out", "ntt_io_write_out",
     "ntt_profile_enable", "ntt_profile_read",
 ]
@@ -98,6 +98,7 @@ class NttLibrary:
         L.ntt64_poly_multiply_batched_device.restype = ci
         L.ntt_transform_u64.argtypes = [c_u64p, ci, ci, u64]; L.ntt_transform_u64.restype = ci
         L.ntt_transform_device_u64.argtypes = [vp, sz, sz, ci, u64, vp]; L.ntt_transform_device_u64.restype = ci
+        L.ntt_transform_device_u32.argtypes = [vp, sz, sz, ci, ctypes.c_uint32, vp]; L.ntt_transform_device_u32.restype = ci
         i64 = ctypes.c_int64
         L.ntt_io_read_header.argtypes = [ctypes.c_char_p, ctypes.POINTER(i64), ctypes.POINTER(u64)]; L.ntt_io_read_header.restype = ci
         L.ntt_io_read_in.argtypes = [ctypes.c_char_p, c_u64p, c_u64p, i64, ci]; L.ntt_io_read_in.restype = ci

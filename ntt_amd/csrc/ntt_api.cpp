@@ -34,6 +34,7 @@
 #include "../../include/ntt_amd.h"
 #include "ntt_kernels.h"
 #include "ntt_kernels64.h"
+#include "ntt_transform32.h"
 #include "ntt_plan.h"
 
 using namespace nttamd;
@@ -110,6 +111,7 @@ struct Plan {
     DevBuf tables;
     const uint32_t *twF = nullptr, *twI = nullptr, *ow = nullptr, *T1 = nullptr, *T3 = nullptr;
     CoreTables core{};
+    CoreTables core_t{};   // the same with the inverse table scaled for the stand-alone transform
     RoundTables32 rt{};
 };
 
@@ -293,7 +295,7 @@ int get_plan(Device* dev, uint32_t p, int logL, Plan** out) {
     PlanHost& h = pl->h;
     size_t o_twF = stage(img, h.twF), o_twI = stage(img, h.twI), o_ow = stage(img, h.ow);
     size_t o_1F = stage(img, h.tw1F), o_2F = stage(img, h.tw2F), o_1I = stage(img, h.tw1I), o_2I = stage(img, h.tw2I);
-    size_t o_T1 = stage(img, h.T1), o_T3 = stage(img, h.T3);
+    size_t o_T1 = stage(img, h.T1), o_T3 = stage(img, h.T3), o_1It = stage(img, h.tw1I_t);
     size_t o_rtF[13] = {0}, o_rtI[13] = {0};
     for (int b = 0; b < 13; ++b) { o_rtF[b] = stage(img, h.rtF[b]); o_rtI[b] = stage(img, h.rtI[b]); }
     if (img.empty()) img.push_back(0);
@@ -304,6 +306,7 @@ int get_plan(Device* dev, uint32_t p, int logL, Plan** out) {
     pl->twF = base + o_twF; pl->twI = base + o_twI; pl->ow = base + o_ow;
     pl->core.tw1F = base + o_1F; pl->core.tw2F = base + o_2F; pl->core.tw1I = base + o_1I; pl->core.tw2I = base + o_2I;
     pl->T1 = base + o_T1; pl->T3 = base + o_T3;
+    pl->core_t = pl->core; pl->core_t.tw1I = base + o_1It;
     for (int b = 0; b < 13; ++b) {
         pl->rt.f[b] = h.rtF[b].empty() ? nullptr : base + o_rtF[b];
         pl->rt.i[b] = h.rtI[b].empty() ? nullptr : base + o_rtI[b];
@@ -514,6 +517,12 @@ bool direct_path_ok(uint64_t p, int logL) {
     const bool ok = modulus_is_ntt_friendly(p, logL);
     if (memo.size() < 4096) memo[key] = ok;
     return ok;
+}
+
+// NTT_TRANSFORM32=off sends every stand-alone transform through the 64-bit field (A/B measurements and tests of that path)
+bool transform32_allowed() {
+    static const bool v = [] { const char* e = getenv("NTT_TRANSFORM32"); return !(e && strcmp(e, "off") == 0); }();
+    return v;
 }
 
 // NTT_CRT_MERGE=separate keeps the recombination a pass of its own (A/B measurements and tests of the stand-alone merge kernel)
@@ -2196,6 +2205,112 @@ int ntt64_poly_multiply_batched_device(const uint64_t* d_a, const uint64_t* d_b,
                                   (hipStream_t)stream);
 }
 
+}  // extern "C"
+
+namespace {
+
+// Natural-order transform on the 32-bit kernels (ntt_transform32.h), in place on rows of n = 2^lg values of type T.
+// *served = false (and nothing launched) when this modulus / length belongs to the 64-bit field instead.
+template <int Q, bool LZ, typename T>
+void launch_transform32_columns(const Plan& pl, T* d_a, uint32_t* work, size_t n, size_t batch, bool invert, hipStream_t st) {
+    constexpr int MINW = multipass_minw(Q);
+    const unsigned chunks = CORE_N / 256;
+    if (!invert)
+        NTT_LAUNCH_P("k_fwd_strided", (k_fwd_strided<Q, LZ, false, false, MINW, T>), dim3((unsigned)(chunks * batch), 1, 1), dim3(256), st,
+                     (const T*)d_a, (const T*)d_a, n, n, (int)n, work, work, CORE_N, pl.T1, pl.h.fc);
+    else
+        NTT_LAUNCH_P("k_inv_strided", (k_inv_strided<Q, LZ, true, false, MINW, T>), dim3((unsigned)(chunks * batch)), dim3(256), st,
+                     (const uint32_t*)work, d_a, n, (int)n, CORE_N, pl.T3, pl.h.fc);
+}
+
+template <bool LZ, typename T>
+int transform32_launch(Device* dev, const Plan& pl, T* d_a, int lg, size_t batch, bool invert, hipStream_t st) {
+    const size_t n = (size_t)1 << lg;
+    if (lg <= 12) {
+        if (pl.h.small16) {
+            const size_t per_wg = (size_t)1 << (12 - lg);
+            const unsigned grid = (unsigned)((batch + per_wg - 1) / per_wg);
+            if (!invert) NTT_LAUNCH_P("k_ntt_small16", (k_ntt_small16<LZ, false, T>), dim3(grid), dim3(CORE_T), st, d_a, lg, batch, pl.h.scale_t, pl.h.fc, pl.rt);
+            else NTT_LAUNCH_P("k_ntt_small16", (k_ntt_small16<LZ, true, T>), dim3(grid), dim3(CORE_T), st, d_a, lg, batch, pl.h.scale_t, pl.h.fc, pl.rt);
+        } else {
+            const unsigned threads = n / 2 < 64 ? 64u : (n / 2 > 256 ? 256u : (unsigned)(n / 2));
+            if (!invert) NTT_LAUNCH_P("k_ntt_small2", (k_ntt_small2<LZ, false, T>), dim3((unsigned)batch), dim3(threads), st, d_a, lg, pl.twF, pl.h.scale_t, pl.h.fc);
+            else NTT_LAUNCH_P("k_ntt_small2", (k_ntt_small2<LZ, true, T>), dim3((unsigned)batch), dim3(threads), st, d_a, lg, pl.twI, pl.h.scale_t, pl.h.fc);
+        }
+        HIP_TRY(hipGetLastError());
+        return NTT_OK;
+    }
+    // longer transforms: three passes through a 32-bit work array of the same shape
+    void* ws = nullptr;
+    int rc = dev->workspace_for(st, batch * n * sizeof(uint32_t), &ws);
+    if (rc != NTT_OK) return rc;
+    uint32_t* work = (uint32_t*)ws;
+    const int Q = lg - 12;
+    const unsigned rows = (unsigned)(batch << Q);
+    auto columns = [&]() {
+        switch (Q) {
+            case 1:
+                if (!invert) NTT_LAUNCH_P("k_ntt_outer2", (k_ntt_outer2<LZ, false, T>), dim3((unsigned)(16 * batch)), dim3(256), st, work, d_a, pl.ow, pl.h.fc);
+                else NTT_LAUNCH_P("k_ntt_outer2", (k_ntt_outer2<LZ, true, T>), dim3((unsigned)(16 * batch)), dim3(256), st, work, d_a, pl.ow, pl.h.fc);
+                break;
+            case 2: launch_transform32_columns<2, LZ, T>(pl, d_a, work, n, batch, invert, st); break;
+            case 3: launch_transform32_columns<3, LZ, T>(pl, d_a, work, n, batch, invert, st); break;
+            case 4: launch_transform32_columns<4, LZ, T>(pl, d_a, work, n, batch, invert, st); break;
+            case 5: launch_transform32_columns<5, LZ, T>(pl, d_a, work, n, batch, invert, st); break;
+            default: launch_transform32_columns<6, LZ, T>(pl, d_a, work, n, batch, invert, st); break;
+        }
+    };
+    if (!invert) {
+        columns();
+        NTT_LAUNCH_P("k_ntt_core_fwd", (k_ntt_core_fwd<LZ>), dim3(rows), dim3(CORE_T), st, work, pl.h.fc, pl.core);
+        NTT_LAUNCH_P("k_ntt_transpose", (k_ntt_transpose<LZ, false, T>), dim3(rows), dim3(256), st, work, d_a, Q, pl.h.fc);
+    } else {
+        NTT_LAUNCH_P("k_ntt_transpose", (k_ntt_transpose<LZ, true, T>), dim3(rows), dim3(256), st, work, d_a, Q, pl.h.fc);
+        NTT_LAUNCH_P("k_ntt_core_inv", (k_ntt_core_inv<LZ>), dim3(rows), dim3(CORE_T), st, work, pl.h.fc, pl.core_t);
+        columns();
+    }
+    HIP_TRY(hipGetLastError());
+    return NTT_OK;
+}
+
+template <typename T>
+int transform32_device(Device* dev, T* d_a, size_t n, size_t batch, bool invert, uint64_t p, hipStream_t st, bool* served) {
+    *served = false;
+    const int lg = ceil_log2(n);
+    if (lg < 1 || lg > 18 || p >= (1ull << 31) || !direct_path_ok(p, lg)) return NTT_OK;
+    if (batch > ((size_t)1 << 24)) return NTT_OK;
+    Plan* pl = nullptr;
+    int rc = get_plan(dev, (uint32_t)p, lg, &pl);
+    if (rc != NTT_OK) return rc;
+    *served = true;
+    return pl->h.lazy ? transform32_launch<true, T>(dev, *pl, d_a, lg, batch, invert, st)
+                      : transform32_launch<false, T>(dev, *pl, d_a, lg, batch, invert, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ntt_transform_device_u32(uint32_t* d_a, size_t n, size_t batch, int invert, uint32_t p, void* stream) {
+    NTT_API_LOCK;
+    if (!d_a) return fail(NTT_ERR_ARG, "null pointer");
+    if (n < 1 || (n & (n - 1)) != 0) return fail(NTT_ERR_ARG, "transform length must be a power of two");
+    int rc = do_init(0);
+    if (rc != NTT_OK) return rc;
+    if (batch == 0 || n == 1) return NTT_OK;       // a length-1 transform is the identity (values are taken as reduced)
+    Device* dev = nullptr;
+    if ((rc = current_device(&dev)) != NTT_OK) return rc;
+    bool served = false;
+    if ((rc = transform32_device<uint32_t>(dev, d_a, n, batch, invert != 0, p, (hipStream_t)stream, &served)) != NTT_OK) return rc;
+    if (!served) {
+        std::string why;
+        if (n > ((size_t)1 << 18)) why = "32-bit transforms go up to 2^18 points (ntt_transform_device_u64 serves longer ones)";
+        else modulus_is_ntt_friendly(p, ceil_log2(n), &why);
+        return fail(NTT_ERR_MODULUS, "32-bit transform: " + why);
+    }
+    return NTT_OK;
+}
+
 // ---- stand-alone transforms in natural order (the reference's NTT(), main_naive.cc:96-137) ----
 int ntt_transform_device_u64(uint64_t* d_a, size_t n, size_t batch, int invert, uint64_t p, void* stream) {
     NTT_API_LOCK;
@@ -2217,9 +2332,13 @@ int ntt_transform_device_u64(uint64_t* d_a, size_t n, size_t batch, int invert, 
     Device* dev = nullptr;
     if ((rc = current_device(&dev)) != NTT_OK) return rc;
     const int lg = ceil_log2(n);
+    hipStream_t st = (hipStream_t)stream;
+    if (transform32_allowed()) {      // moduli below 2^31: the 32-bit kernels, 8-byte words only at the two ends
+        bool served = false;
+        if ((rc = transform32_device<uint64_t>(dev, d_a, n, batch, invert != 0, p, st, &served)) != NTT_OK || served) return rc;
+    }
     Plan64* pl = nullptr;
     if ((rc = get_plan64(dev, p, lg, &pl)) != NTT_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
     const uint64_t total = (uint64_t)batch * n;
     load64(*pl, (const uint64_t*)d_a, (size_t)n, (uint64_t)n, d_a, (uint64_t)n, (uint64_t)batch, st);
     uint64_t scale = 1;

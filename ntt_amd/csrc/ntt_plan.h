@@ -102,27 +102,30 @@ struct PlanHost {
     int Q = 0;          // multipass: log2 of the strided radix (L = 4096 << Q)
     FieldConsts fc{};
     uint32_t scale_m = 0;             // Montgomery form of L^-1 * R
+    uint32_t scale_t = 0;             // Montgomery form of L^-1 (stand-alone inverse transform: no pointwise product to undo)
     std::vector<uint32_t> twF, twI;   // small: wL^(+-e), e < L/2
     bool small16 = false;             // small: the radix-16 kernel applies (L >= 32 and 64 | p-1)
     std::vector<uint32_t> rtF[13], rtI[13];   // small16: round tables for blocks of 2^b, b = 5..logL
     std::vector<uint32_t> tw1F, tw2F, tw1I, tw2I;  // core tables
+    std::vector<uint32_t> tw1I_t;     // tw1I with the scale of the stand-alone inverse transform (L^-1)
     std::vector<uint32_t> ow;         // fused8192: [w8192^j | w8192^-j], j < 4096
     std::vector<uint32_t> T1, T3;     // multipass strided twiddles, L entries each
 };
 
-inline void fill_core_tables(PlanHost& h, uint64_t scale /* plain value folded into tw1I */) {
+inline void fill_core_tables(PlanHost& h, uint64_t scale /* plain value folded into tw1I */, uint64_t scale_t /* into tw1I_t */) {
     const uint32_t p = h.p;
     const uint64_t w4096 = h_powmod(3, (p - 1) / 4096, p), w4096i = h_powmod(w4096, p - 2, p);
     const uint64_t w256 = h_powmod(w4096, 16, p), w256i = h_powmod(w256, p - 2, p);
-    h.tw1F.resize(256 * 16); h.tw1I.resize(256 * 16); h.tw2F.resize(16 * 16); h.tw2I.resize(16 * 16);
+    h.tw1F.resize(256 * 16); h.tw1I.resize(256 * 16); h.tw2F.resize(16 * 16); h.tw2I.resize(16 * 16); h.tw1I_t.resize(256 * 16);
     for (int pos = 0; pos < 16; ++pos) {
         const int k = bitrev(pos, 4);
         const uint64_t stepF = h_powmod(w4096, k, p), stepI = h_powmod(w4096i, k, p);
-        uint64_t vF = 1, vI = scale % p;
+        uint64_t vF = 1, vI = scale % p, vT = scale_t % p;
         for (int t = 0; t < 256; ++t) {
             h.tw1F[t * 16 + pos] = h_mont(vF, p);
             h.tw1I[t * 16 + pos] = h_mont(vI, p);
-            vF = h_mulmod(vF, stepF, p); vI = h_mulmod(vI, stepI, p);
+            h.tw1I_t[t * 16 + pos] = h_mont(vT, p);
+            vF = h_mulmod(vF, stepF, p); vI = h_mulmod(vI, stepI, p); vT = h_mulmod(vT, stepI, p);
         }
         const uint64_t s2F = h_powmod(w256, k, p), s2I = h_powmod(w256i, k, p);
         uint64_t uF = 1, uI = 1;
@@ -156,6 +159,7 @@ inline bool build_plan_host(uint32_t p, int logL, PlanHost& h, std::string* err)
     const uint64_t Linv = h_powmod(L % p, p - 2, p);
     const uint64_t scale = h_mulmod(Linv, R1, p);  // L^-1 * R: undoes the R^-1 of the pointwise product
     h.scale_m = h_mont(scale, p);
+    h.scale_t = h_mont(Linv, p);
     if (logL <= 12) {
         h.kind = PLAN_SMALL;
         h.twF.resize(L / 2 ? L / 2 : 1); h.twI.resize(h.twF.size());
@@ -185,7 +189,7 @@ inline bool build_plan_host(uint32_t p, int logL, PlanHost& h, std::string* err)
         }
     } else if (logL == 13) {
         h.kind = PLAN_FUSED8192;
-        fill_core_tables(h, scale);
+        fill_core_tables(h, scale, Linv);
         h.ow.resize(8192);
         uint64_t a = 1, b = 1;
         for (int j = 0; j < 4096; ++j) {
@@ -196,7 +200,7 @@ inline bool build_plan_host(uint32_t p, int logL, PlanHost& h, std::string* err)
         h.kind = PLAN_MULTIPASS;
         if (logL > 18) { if (err) *err = "transform lengths above 2^18 are not implemented yet"; return false; }
         h.Q = logL - 12;
-        fill_core_tables(h, scale);
+        fill_core_tables(h, scale, Linv);
         const int R = 1 << h.Q;
         const uint64_t C = L >> h.Q;
         h.T1.resize(L); h.T3.resize(L);

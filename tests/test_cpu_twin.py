@@ -301,6 +301,28 @@ def test_standalone_transform_matches_reference_ntt(twin, oracle):
         twin.transform_u64(np.ones(12, dtype=np.uint64), False, 998244353)   # not a power of two
 
 
+def test_natural_order_transform_on_32_bit_residues(twin, oracle):
+    """the 32-bit transform kernels (ntt_transform32.h) for every length 2 .. 2^18 and both entry points; 257 and 65537
+    have no 64th / short 2-power roots beyond their size and take the radix-2 kernel"""
+    rng = np.random.default_rng(137)
+    for p in (7340033, 998244353, 1224736769, 257, 65537):
+        for lg in range(1, 19):
+            n = 1 << lg
+            if (p - 1) % n:
+                continue
+            batch = 3 if lg <= 13 else 1
+            x = rng.integers(0, p, (batch, n), dtype=np.uint64)
+            x[0, 0] = p - 1
+            for inv in (0, 1):
+                want = np.stack([oracle.ntt(x[r], bool(inv), p) for r in range(batch)])
+                y = x.astype(np.uint32).copy()
+                twin.check(twin.lib.ntt_transform_device_u32(y.ctypes.data, n, batch, inv, p, None))
+                assert np.array_equal(y.astype(np.uint64), want), (p, lg, inv)
+                z = x.copy()
+                twin.check(twin.lib.ntt_transform_device_u64(z.ctypes.data, n, batch, inv, p, None))
+                assert np.array_equal(z, want), (p, lg, inv)
+
+
 def test_host_u64_path_narrows_reduced_inputs_and_reduces_the_rest(twin, oracle):
     # reduced inputs below a 31-bit modulus travel as 32-bit words; a single value >= p sends the call down the
     # 64-bit loads, which reduce it -- both must give the product of the residues

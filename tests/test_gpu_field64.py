@@ -1,8 +1,11 @@
 """GPU parity of the 64-bit-field path (direct product and explicit four-step), through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 BIGP = 1337006139375617  # 19 * 2^46 + 1, the reference's large modulus (main_naive.cc:234)
 
@@ -141,6 +144,8 @@ def test_long_product_beyond_the_crt_bound(gpu_lib):
 
 @pytest.mark.parametrize("p", [7340033, 998244353, 1224736769])
 def test_standalone_transform_matches_reference_ntt(gpu_lib, oracle, p):
+    # these moduli take the 32-bit kernels; the 64-bit-field transform is checked on the same moduli in the next test (the
+    # reference's NTT(), which the oracle restates, is only defined for moduli below 2^32)
     rng = np.random.default_rng(p % 31)
     for n in (1, 2, 8, 512, 4096, 8192, 1 << 16, 1 << 18):
         x = rng.integers(0, p, n, dtype=np.uint64)
@@ -148,6 +153,29 @@ def test_standalone_transform_matches_reference_ntt(gpu_lib, oracle, p):
         assert np.array_equal(fwd, oracle.ntt(x, False, p)), n
         assert np.array_equal(gpu_lib.transform_u64(x, True, p), oracle.ntt(x, True, p)), n
         assert np.array_equal(gpu_lib.transform_u64(fwd, True, p), x)
+
+
+def test_standalone_transform_of_small_moduli_in_the_64_bit_field():
+    """NTT_TRANSFORM32=off (fresh process: the switch is read once) keeps moduli below 2^31 on the 64-bit-field transform,
+    which must give the same natural-order results."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from ntt_amd._binding import load_product_library
+        from oracle_binding import Oracle
+        lib = load_product_library(); lib.init(0); orc = Oracle()
+        rng = np.random.default_rng(3)
+        ok = True
+        for p in (7340033, 998244353, 1224736769):
+            for n in (2, 64, 4096, 8192, 1 << 16):
+                x = rng.integers(0, p, n, dtype=np.uint64)
+                ok = ok and np.array_equal(lib.transform_u64(x, False, p), orc.ntt(x, False, p))
+                ok = ok and np.array_equal(lib.transform_u64(x, True, p), orc.ntt(x, True, p))
+        print("RESULT", ok)
+    """) % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NTT_TRANSFORM32="off"), capture_output=True, text=True, timeout=300)
+    assert "RESULT True" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
 
 
 def test_standalone_transform_batched_device(gpu_lib, oracle):

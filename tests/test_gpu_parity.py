@@ -288,3 +288,42 @@ def test_crt_merge_against_python_integers(gpu_lib):
 
     for p in cm.MODULI:
         cm.check(gpu_lib, to_dev, from_dev, p, xs)
+
+
+@pytest.mark.parametrize("p", PRIMES32)
+def test_natural_order_transform_on_32_bit_residues(gpu_lib, oracle, p):
+    """ntt_transform_device_u32 / _u64 = the reference's NTT(a, n, invert, p, 3) (main_naive.cc:96-137: bit reversal, radix-2
+    stages, n^-1 scaling of the inverse) for every length 2 .. 2^18 that divides p - 1, several rows per call, both
+    directions, and forward followed by inverse gives the input back."""
+    import torch
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(p % 1009)
+    for lg in range(1, 19):
+        n = 1 << lg
+        if (p - 1) % n:
+            continue
+        batch = 5 if lg <= 12 else (3 if lg <= 14 else 2)
+        x = rand(rng, p, (batch, n))
+        x[0, :] = p - 1                                      # the largest residues exercise the lazy ranges
+        for inv in (0, 1):
+            want = np.stack([oracle.ntt(x[r], bool(inv), p) for r in range(batch)])
+            t32 = torch.from_numpy(x.astype(np.uint32).view(np.int32)).cuda()
+            gpu_lib.check(gpu_lib.lib.ntt_transform_device_u32(t32.data_ptr(), n, batch, inv, p, st))
+            t64 = torch.from_numpy(x.view(np.int64).copy()).cuda()
+            gpu_lib.check(gpu_lib.lib.ntt_transform_device_u64(t64.data_ptr(), n, batch, inv, p, st))
+            torch.cuda.synchronize()
+            assert np.array_equal(t32.cpu().numpy().view(np.uint32).astype(np.uint64), want), (lg, inv)
+            assert np.array_equal(t64.cpu().numpy().view(np.uint64), want), (lg, inv)
+            if not inv:      # and back
+                gpu_lib.check(gpu_lib.lib.ntt_transform_device_u32(t32.data_ptr(), n, batch, 1, p, st))
+                torch.cuda.synchronize()
+                assert np.array_equal(t32.cpu().numpy().view(np.uint32).astype(np.uint64), x), lg
+
+
+def test_natural_order_transform_argument_errors(gpu_lib):
+    import torch
+    from ntt_amd._binding import NttError
+    t = torch.zeros(64, dtype=torch.int32, device="cuda")
+    for n, p in ((48, 998244353), (64, 1000000007), (1 << 19, 998244353)):      # not a power of two / unfriendly modulus / too long
+        with pytest.raises(NttError):
+            gpu_lib.check(gpu_lib.lib.ntt_transform_device_u32(t.data_ptr(), n, 1, 0, p, None))
