@@ -62,6 +62,18 @@ NTT_HD uint32_t redc_lazy(uint64_t T, uint32_t p, uint32_t np) {
 // x - m if x >= m else x, for x < 2m.
 NTT_HD uint32_t csub(uint32_t x, uint32_t m) { return x >= m ? x - m : x; }
 
+// x of the lane of the own quad (four consecutive lanes) that the DPP quad permutation `ctrl` names (two selector bits per
+// lane: 0xB1 = lanes 1,0,3,2, i.e. lane ^ 1; 0x4E = lanes 2,3,0,1, i.e. lane ^ 2): one full-rate vector instruction, no LDS.
+// Uniform control flow only.  (The CPU build of the test suite supplies a stand-in; the host pass of the HIP compiler
+// never executes it.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NTT_QUAD_PERM(x, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xF, 0xF, false))
+#elif defined(NTT_CPU_TWIN)
+#define NTT_QUAD_PERM(x, ctrl) hipshim::quad_perm((x), (ctrl))
+#else
+#define NTT_QUAD_PERM(x, ctrl) (x)
+#endif
+
 // Compile-time loop: f(integral_constant<int, I>) for I in [I0, N).  The register transforms below
 // index their arrays only with these constants, so the arrays stay in registers whatever the
 // optimiser's unrolling limits are.

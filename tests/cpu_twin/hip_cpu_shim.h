@@ -83,6 +83,21 @@ inline void yield_barrier() {
     State& s = st();
     swapcontext(&s.fibers[s.current], &s.sched);
 }
+// A DPP quad permutation (every lane reads `x` of the lane of its own quad that `ctrl` names: two selector bits per
+// lane) for fibres: all threads of the workgroup must reach it together, as they do on the GPU, where it is one
+// instruction of a wavefront in uniform control flow.
+inline uint32_t quad_perm(uint32_t x, int ctrl) {
+    static thread_local std::vector<uint32_t> lanes;
+    State& s = st();
+    const int T = (int)(s.blockDim.x * s.blockDim.y * s.blockDim.z);
+    if ((int)lanes.size() < T) lanes.resize(T);
+    const int me = s.current;
+    lanes[me] = x;
+    yield_barrier();
+    const uint32_t v = lanes[(me & ~3) | ((ctrl >> (2 * (me & 3))) & 3)];
+    yield_barrier();
+    return v;
+}
 }  // namespace hipshim
 
 #define threadIdx (hipshim::st().threadIdx)

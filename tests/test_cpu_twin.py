@@ -15,9 +15,23 @@ BIGP = 1337006139375617
 @pytest.mark.parametrize("p", [7340033, 104857601, 469762049, 998244353, 1004535809, 1224736769])
 def test_direct_path_all_size_classes(twin, oracle, p):
     rng = np.random.default_rng(p % 97)
-    for n in (1, 2, 4, 8, 64, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072):
+    for n in (1, 2, 4, 8, 16, 32, 64, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072):
         a = rng.integers(0, p, n, dtype=np.uint64); b = rng.integers(0, p, n, dtype=np.uint64)
         assert np.array_equal(twin.multiply_u64(a, b, p), oracle.ntt_multiply(a, b, p)), n
+
+
+@pytest.mark.parametrize("p", [7340033, 998244353, 1224736769])
+def test_short_products_exchanged_inside_the_quad(twin, oracle, p):
+    """transform lengths 32 and 64 (n = 9 .. 32): the levels that run on registers exchanged between neighbouring lanes,
+    several products per workgroup, batches that do not fill the last workgroup"""
+    rng = np.random.default_rng(p % 89)
+    for n in (9, 12, 16, 17, 24, 31, 32):
+        for batch in (1, 3, 130):
+            a = rng.integers(0, p, (batch, n), dtype=np.uint32); b = rng.integers(0, p, (batch, n), dtype=np.uint32)
+            a[0] = p - 1; b[0] = p - 1
+            got = twin.multiply_batched(a, b, p)
+            want = np.stack([oracle.schoolbook_u64(a[r].astype(np.uint64), b[r].astype(np.uint64), p) for r in range(batch)])
+            assert np.array_equal(got.astype(np.uint64), want), (n, batch)
 
 
 def test_golden_vectors(twin, route):

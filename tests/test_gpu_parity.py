@@ -327,3 +327,20 @@ def test_natural_order_transform_argument_errors(gpu_lib):
     for n, p in ((48, 998244353), (64, 1000000007), (1 << 19, 998244353)):      # not a power of two / unfriendly modulus / too long
         with pytest.raises(NttError):
             gpu_lib.check(gpu_lib.lib.ntt_transform_device_u32(t.data_ptr(), n, 1, 0, p, None))
+
+
+@pytest.mark.parametrize("p", [7340033, 998244353, 1224736769])
+def test_short_products_exchanged_inside_the_quad(gpu_lib, oracle, p):
+    """transform lengths 32 and 64 (n = 9 .. 32): the last levels, the pointwise product and the first inverse levels run on
+    registers exchanged between neighbouring lanes with DPP permutes (the butterflies of main.cc:926-995 at lane distance 1
+    and 2); several products per workgroup, batches that do not fill the last workgroup"""
+    rng = np.random.default_rng(p % 89)
+    for n in (9, 12, 16, 17, 24, 31, 32):
+        for batch in (1, 3, 130, 4099):
+            a = rng.integers(0, p, (batch, n), dtype=np.uint32); b = rng.integers(0, p, (batch, n), dtype=np.uint32)
+            a[0] = p - 1; b[0] = p - 1
+            got = gpu_lib.multiply_batched(a, b, p)
+            pick = sorted(set([0, 1, batch - 1] + list(range(0, batch, 97))))
+            pick = [r for r in pick if r < batch]
+            for r in pick:
+                assert np.array_equal(got[r].astype(np.uint64), oracle.schoolbook_u64(a[r].astype(np.uint64), b[r].astype(np.uint64), p)), (n, batch, r)

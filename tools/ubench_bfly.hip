@@ -18,6 +18,11 @@ __device__ __forceinline__ uint32_t csub_min(uint32_t x, uint32_t m) { uint32_t 
 __device__ __forceinline__ uint32_t csub_sel(uint32_t x, uint32_t m) { return x >= m ? x - m : x; }
 __device__ __forceinline__ uint32_t csub_asr(uint32_t x, uint32_t m) { int32_t t = (int32_t)(x - m); return (uint32_t)t + (m & (uint32_t)(t >> 31)); }
 
+// 24 x 24 -> 48-bit product, low 32 bits and bits 32..47 (the masks fold into v_mul_u32_u24 / v_mul_hi_u32_u24, which read
+// only the low 24 bits of their operands)
+__device__ __forceinline__ uint32_t mul24_lo(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+__device__ __forceinline__ uint32_t mul24_hi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)) >> 32); }
+
 template <int V>
 __device__ __forceinline__ void bfly(uint32_t& u, uint32_t& v, uint32_t w, uint32_t w2, const F& f) {
     // DIF (Gentleman-Sande): u' = u+v mod, v' = (u-v)*w
@@ -42,6 +47,18 @@ __device__ __forceinline__ void bfly(uint32_t& u, uint32_t& v, uint32_t w, uint3
     }
     if (V == 6) {  // no multiply (add/sub/cond-sub cost only)
         u = csub_min(s, f.p2); v = csub_min(d, f.p2);
+    }
+    if (V == 7) {  // moduli below 2^23: Montgomery with R = 2^24 on the 24-bit multipliers (v_mul_u32_u24 / v_mul_hi_u32_u24)
+        // f.ninv holds -p^-1 mod 2^24 here.  The difference is brought below 2^24 first (the multipliers take 24 bits).
+        u = csub_min(s, f.p2);
+        const uint32_t dr = csub_min(d, f.p2);
+        const uint32_t t_lo = mul24_lo(dr, w);                 // bits 0..31 of the 48-bit product
+        const uint32_t t_hi = mul24_hi(dr, w);               // bits 32..47
+        const uint32_t m = mul24_lo(t_lo, f.ninv);             // only its low 24 bits are used below
+        const uint32_t q_lo = mul24_lo(m, f.p), q_hi = mul24_hi(m, f.p);
+        // (T + m p) >> 24: the low 24 bits cancel, a carry comes out of them exactly when they are not zero
+        const uint32_t a = __builtin_amdgcn_alignbit(t_hi, t_lo, 24), b = __builtin_amdgcn_alignbit(q_hi, q_lo, 24);
+        v = a + b + ((t_lo & 0xFFFFFFu) != 0 ? 1u : 0u);
     }
 }
 
@@ -103,6 +120,19 @@ int main() {
         run<4>("mont-sub(w*pinv) + csub_min", w, d_out, d_tw, f);
         run<5>("redc64, no csub", w, d_out, d_tw, f);
         run<6>("no mult, 2 csub", w, d_out, d_tw, f);
+    }
+    {   // the 23-bit modulus of the reference's first data sets, R = 2^24
+        F g; g.p = 7340033u; g.p2 = 2 * g.p;
+        uint32_t inv = g.p;                                   // Newton: p^-1 mod 2^32, then negated and cut to 24 bits
+        for (int i = 0; i < 5; ++i) inv *= 2u - g.p * inv;
+        g.ninv = (0u - inv) & 0xFFFFFFu;
+        uint32_t h2[16];
+        for (int i = 0; i < 16; ++i) h2[i] = (i * 7919u + 12345u) % g.p;
+        CHECK(hipMemcpy(d_tw, h2, 64, hipMemcpyHostToDevice));
+        for (int w : {2, 4, 8}) {
+            run<0>("p=7340033 redc64 + csub_min", w, d_out, d_tw, g);
+            run<7>("p=7340033 u24 Montgomery", w, d_out, d_tw, g);
+        }
     }
     return 0;
 }
