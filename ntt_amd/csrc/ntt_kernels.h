@@ -531,8 +531,11 @@ __device__ __forceinline__ void pair_transpose16(uint32_t (&r)[16], int lane) {
     for (int m = 0; m < 8; ++m) quad_pair_swap<1>(r[2 * m], r[2 * m + 1], lane);
 }
 
+#ifndef NTT_SMALL16_WAVES
+#define NTT_SMALL16_WAVES 1
+#endif
 template <bool LZ, typename TIn, typename TOut>
-__global__ void __launch_bounds__(CORE_T) k_small16(const TIn* A, const TIn* Bp, TOut* out, size_t a_stride, size_t b_stride,
+__global__ void __launch_bounds__(CORE_T, NTT_SMALL16_WAVES) k_small16(const TIn* A, const TIn* Bp, TOut* out, size_t a_stride, size_t b_stride,
                                                     size_t out_stride, int n, int n_out, int logL, size_t batch,
                                                     uint32_t scale_m, FieldConsts fc, RoundTables32 rt) {
     __shared__ uint32_t la[CORE_N];
@@ -542,7 +545,10 @@ __global__ void __launch_bounds__(CORE_T) k_small16(const TIn* A, const TIn* Bp,
     const int ql = ((logL - 1) & 3) + 1;
     const size_t first = (size_t)blockIdx.x << (12 - logL);     // first product of this workgroup
     uint32_t a[16], b[16];
-    // operands -> LDS, zero padded (values beyond n, products beyond the batch)
+    // operands -> LDS, zero padded (values beyond n, products beyond the batch).  All thirty-two loads of a thread are
+    // requested before the first value is used, and none is conditional (padding reads the operand's first word and is
+    // replaced by zero afterwards): loads inside a condition, each followed by its LDS write, waited for one another --
+    // sixteen memory round trips in a row, which held every length at 1.4 TB/s.
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         int e = t + CORE_T * i;
@@ -550,9 +556,19 @@ __global__ void __launch_bounds__(CORE_T) k_small16(const TIn* A, const TIn* Bp,
         const size_t prod = first + (size_t)(e >> logL);
         const int idx = e & ((1 << logL) - 1);
         const bool inside = prod < batch && idx < n;
+        a[i] = load_coeff<LZ>(A, inside ? prod * a_stride + (size_t)idx : 0, f, fc);
+        b[i] = load_coeff<LZ>(Bp, inside ? prod * b_stride + (size_t)idx : 0, f, fc);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int e = t + CORE_T * i;
+        NTT_OPAQUE(e);
+        const size_t prod = first + (size_t)(e >> logL);
+        const int idx = e & ((1 << logL) - 1);
+        const bool inside = prod < batch && idx < n;
         const int s = small_slot(e);
-        la[s] = inside ? load_coeff<LZ>(A + prod * a_stride, (size_t)idx, f, fc) : 0u;
-        lb[s] = inside ? load_coeff<LZ>(Bp + prod * b_stride, (size_t)idx, f, fc) : 0u;
+        la[s] = inside ? a[i] : 0u;
+        lb[s] = inside ? b[i] : 0u;
     }
     __syncthreads();
     if (logL <= 6) {

@@ -38,12 +38,12 @@ NTT_HD int nat_slot(int K) { return K ^ ((K >> 5) & 31); }
 // any value of the caller's array -> [0, B): 32-bit words are reduced by one multiplication with the Montgomery form of 1
 // (they may be anything below 2^32), 64-bit words by reduce64
 template <bool LZ>
-__device__ __forceinline__ uint32_t load_any(const uint32_t* src, size_t idx, const Field<LZ>& f, const FieldConsts& fc) {
-    return f.mulw(src[idx], fc.r1);
-}
+__device__ __forceinline__ uint32_t reduce_any(uint32_t x, const Field<LZ>& f, const FieldConsts& fc) { return f.mulw(x, fc.r1); }
 template <bool LZ>
-__device__ __forceinline__ uint32_t load_any(const uint64_t* src, size_t idx, const Field<LZ>& f, const FieldConsts& fc) {
-    return f.reduce64(src[idx], fc.r1, fc.r2);
+__device__ __forceinline__ uint32_t reduce_any(uint64_t x, const Field<LZ>& f, const FieldConsts& fc) { return f.reduce64(x, fc.r1, fc.r2); }
+template <bool LZ, typename T>
+__device__ __forceinline__ uint32_t load_any(const T* src, size_t idx, const Field<LZ>& f, const FieldConsts& fc) {
+    return reduce_any<LZ>(src[idx], f, fc);
 }
 
 // ---------------------------------------------------------------------------
@@ -210,11 +210,15 @@ __global__ void __launch_bounds__(CORE_T) k_ntt_small16(T* data, int lg, size_t 
     // position e = 16 t + i of a thread <-> natural position inside the workgroup's 4096 values
     auto natural_of = [&](int e) -> int { return (e & ~mask) | brev_low(e & mask, lg); };
     if (!INVERSE) {
+        T raw[16];      // all loads requested before the first use, none conditional (see k_small16)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int e = t + CORE_T * i; raw[i] = base[(size_t)e < avail ? e : 0]; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             int e = t + CORE_T * i;
             NTT_OPAQUE(e);
-            la[small_slot(e)] = (size_t)e < avail ? load_any<LZ>(base, (size_t)e, f, fc) : 0u;
+            const uint32_t v = reduce_any<LZ>(raw[i], f, fc);
+            la[small_slot(e)] = (size_t)e < avail ? v : 0u;
         }
         __syncthreads();
         for (int bl = lg; bl > 4; bl -= 4) {
@@ -251,11 +255,15 @@ __global__ void __launch_bounds__(CORE_T) k_ntt_small16(T* data, int lg, size_t 
             if ((size_t)e < avail) base[e] = (T)lb[nat_slot(e)];
         }
     } else {
+        T raw[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int e = t + CORE_T * i; raw[i] = base[(size_t)e < avail ? e : 0]; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             int e = t + CORE_T * i;
             NTT_OPAQUE(e);
-            lb[nat_slot(e)] = (size_t)e < avail ? load_any<LZ>(base, (size_t)e, f, fc) : 0u;
+            const uint32_t v = reduce_any<LZ>(raw[i], f, fc);
+            lb[nat_slot(e)] = (size_t)e < avail ? v : 0u;
         }
         __syncthreads();
 #pragma unroll
