@@ -64,6 +64,12 @@ __device__ __forceinline__ uint32_t load_coeff(const uint64_t* src, size_t idx, 
     return f.reduce64(src[idx], fc.r1, fc.r2);
 }
 
+// the same on a word that has already been loaded
+template <bool LZ>
+__device__ __forceinline__ uint32_t reduce_coeff(uint32_t x, const Field<LZ>&, const FieldConsts&) { return x; }
+template <bool LZ>
+__device__ __forceinline__ uint32_t reduce_coeff(uint64_t x, const Field<LZ>& f, const FieldConsts& fc) { return f.reduce64(x, fc.r1, fc.r2); }
+
 // Coefficient idx of a row that holds only `limit` (>= 1) values, zero beyond.  The address is always a valid one and the
 // zero is selected afterwards: a conditional load would be compiled as a branch per element, which ends the basic
 // block and makes every load wait for the one before it.  Used by the memory-bound column pass; the single-kernel
@@ -386,12 +392,20 @@ __global__ void __launch_bounds__(CORE_T) k_fused8192(const TIn* A, const TIn* B
     const TIn* sa = A + (size_t)blockIdx.x * a_stride;
     const TIn* sb = Bp + (size_t)blockIdx.x * b_stride;
     uint32_t a[16], b[16];
+    // Every group of loads below is requested as a whole before its first value is used, and no load is conditional
+    // (padding reads the row's first word and is replaced by zero afterwards): a load inside a condition together with
+    // its first use -- a reduction, a twiddle multiply -- makes the thread wait for each load in turn.
     // even half
+    {
+        TIn ra[16], rb[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int idx = t + 256 * i;
-        a[i] = idx < n ? load_coeff<LZ>(sa, (size_t)idx, f, fc) : 0u;
-        b[i] = idx < n ? load_coeff<LZ>(sb, (size_t)idx, f, fc) : 0u;
+        for (int i = 0; i < 16; ++i) { const int idx = t + 256 * i; ra[i] = sa[idx < n ? idx : 0]; rb[i] = sb[idx < n ? idx : 0]; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int idx = t + 256 * i;
+            const uint32_t va = reduce_coeff<LZ>(ra[i], f, fc), vb = reduce_coeff<LZ>(rb[i], f, fc);
+            a[i] = idx < n ? va : 0u; b[i] = idx < n ? vb : 0u;
+        }
     }
     core_forward2<LZ>(a, b, lds, lds + CORE_N, f, fc, tb, t);
     core_pointwise<LZ>(a, b, f);
@@ -400,24 +414,37 @@ __global__ void __launch_bounds__(CORE_T) k_fused8192(const TIn* A, const TIn* B
     for (int i = 0; i < 16; ++i) park[t + 256 * i] = a[i];
     __syncthreads();  // the odd half reuses the LDS the even half may still be reading
     // odd half
+    {
+        TIn ra[16], rb[16];
+        uint32_t w[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int idx = t + 256 * i;
-        const uint32_t w = ow[idx];
-        a[i] = idx < n ? f.mulw(load_coeff<LZ>(sa, (size_t)idx, f, fc), w) : 0u;
-        b[i] = idx < n ? f.mulw(load_coeff<LZ>(sb, (size_t)idx, f, fc), w) : 0u;
+        for (int i = 0; i < 16; ++i) {
+            const int idx = t + 256 * i;
+            ra[i] = sa[idx < n ? idx : 0]; rb[i] = sb[idx < n ? idx : 0]; w[i] = ow[idx];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int idx = t + 256 * i;
+            const uint32_t va = f.mulw(reduce_coeff<LZ>(ra[i], f, fc), w[i]), vb = f.mulw(reduce_coeff<LZ>(rb[i], f, fc), w[i]);
+            a[i] = idx < n ? va : 0u; b[i] = idx < n ? vb : 0u;
+        }
     }
     core_forward2<LZ>(a, b, lds, lds + CORE_N, f, fc, tb, t);
     core_pointwise<LZ>(a, b, f);
     core_inverse<LZ>(a, lds, f, fc, tb, t);
     TOut* dst = out + (size_t)blockIdx.x * out_stride;
+    {
+        uint32_t w[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int idx = t + 256 * i;
-        uint32_t x = park[idx], y = a[i];
-        f.dit(x, y, ow[CORE_N + idx]);
-        if (idx < n_out) dst[idx] = (TOut)f.canon_inv(x);
-        if (idx + CORE_N < n_out) dst[idx + CORE_N] = (TOut)f.canon_inv(y);
+        for (int i = 0; i < 16; ++i) w[i] = ow[CORE_N + t + 256 * i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int idx = t + 256 * i;
+            uint32_t x = park[idx], y = a[i];
+            f.dit(x, y, w[i]);
+            if (idx < n_out) dst[idx] = (TOut)f.canon_inv(x);
+            if (idx + CORE_N < n_out) dst[idx + CORE_N] = (TOut)f.canon_inv(y);
+        }
     }
 }
 
