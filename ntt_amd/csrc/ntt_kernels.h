@@ -8,14 +8,21 @@
 // permutation (main_naive.cc:82-95) disappears while the outputs stay
 // identical (canonical residues of the same product).
 //
-//   L <= 4096        k_small       one workgroup per product, radix-2 stages in LDS
-//   L == 8192        k_fused8192   one workgroup per product: outer radix-2 stage in
-//                                  registers + two 4096-point LDS-resident cores
-//   L == 4096 * 2^Q  k_fwd_strided (radix-2^Q columns in registers, twiddle, store)
-//     (Q = 2..6)     k_core_mul    (4096-point forward of A and B, pointwise product,
-//                                   4096-point inverse, all in one workgroup)
-//                    k_inv_strided (twiddle, radix-2^Q inverse columns, canonical store)
-//   p > 2^32         the same pipeline once per CRT prime on 64-bit inputs, then k_crt_merge
+//   L <= 16, or 64 does   k_small       one workgroup per product, radix-2 stages in LDS
+//     not divide p-1
+//   32 <= L <= 4096       k_small16     4096/L products per workgroup, radix-16 register rounds with one LDS exchange
+//                                       between rounds; L = 32 and 64 finish inside a quad of lanes (DPP exchanges)
+//   L == 8192             k_fused8192   one workgroup per product: outer radix-2 stage in registers + two 4096-point
+//                                       LDS-resident cores
+//   L == 4096 * 2^Q       k_fwd_strided (radix-2^Q columns in registers, twiddle, store)
+//     (Q = 2..6)          k_core_mul    (4096-point forward of A and B, pointwise product, 4096-point inverse, all in
+//                                        one workgroup)
+//                         k_inv_strided (twiddle, radix-2^Q inverse columns, canonical store)
+//   four-prime CRT route  (moduli above 2^31 under the reference's route policy, and moduli that are not NTT-friendly)
+//     L >= 2^14           k_fwd_strided_crt (64-bit operands read once, residue step and forward column pass of all
+//                         four primes) -> k_core_mul per prime -> k_inv_strided_crt (inverse column pass of all four
+//                         primes and the recombination; the residues never reach memory)
+//     shorter             the single-kernel paths above once per prime on 64-bit inputs, then k_crt_merge
 //
 // Reference loops these replace: zero-pad/copy main_naive.cc:147-153, butterfly
 // stages :106-128, pointwise product :163-165, n^-1 scaling :131-136, copy-out
