@@ -252,6 +252,7 @@ __global__ void __launch_bounds__(TILE64_T, 4) k64_tile(uint64_t* data, const ui
     if (!INVERSE) {
         uint64_t word[16];
         bool inside[16];
+        const bool upper_empty = SRC_RAW && g.src_valid <= (step << (q - 1));   // uniform: no column has a word in rows >= R/2
         if (q > 4) {      // first round reads memory: rows row0 + m * sub
             const int b = q, sub = 1 << (b - 4);
             const int blk = grp >> (b - 4), j = grp & (sub - 1);
@@ -263,10 +264,12 @@ __global__ void __launch_bounds__(TILE64_T, 4) k64_tile(uint64_t* data, const ui
             if (SRC_RAW) {
                 // The address is always a valid one and the zero is selected afterwards: a conditional load is compiled
                 // as a branch per element, which ends the basic block and makes every load wait for the one before it.
+                // Rows from the middle of the block on are padding for every column when the operand is at most half the
+                // block long (always, when the block is a product's whole transform): they are not even requested then.
 #pragma unroll
                 for (int m = 0; m < 16; ++m, pos += dstep) {
                     inside[m] = pos < g.src_valid;
-                    word[m] = src_row[inside[m] ? pos : 0];
+                    if (m < 8 || !upper_empty) word[m] = src_row[inside[m] ? pos : 0];
                 }
             } else {
 #pragma unroll
@@ -277,8 +280,11 @@ __global__ void __launch_bounds__(TILE64_T, 4) k64_tile(uint64_t* data, const ui
             NTT_FENCE64();
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
-                if (SRC_RAW) { const V r = f.from_raw(word[m]); v[m] = inside[m] ? r : V(0); }
-                else v[m] = f.from_mem(word[m]);
+                if (SRC_RAW) {
+                    if (m < 8 || !upper_empty) { const V r = f.from_raw(word[m]); v[m] = inside[m] ? r : V(0); }
+                } else {
+                    v[m] = f.from_mem(word[m]);
+                }
             }
         }
         for (int b = q; b > 4; b -= 4) {         // rounds over blocks of 2^b rows
@@ -289,7 +295,14 @@ __global__ void __launch_bounds__(TILE64_T, 4) k64_tile(uint64_t* data, const ui
 #pragma unroll
                 for (int m = 0; m < 16; ++m) v[m] = lds[tile_slot(row0 + m * sub)];
             }
-            NTT_MATH64(dif_blocks<F, 4, true>(v, f, rF); v[0] = f.settle(v[0]));
+            if (SRC_RAW && upper_empty && b == q) {
+                // first level against zeros: (u, 0) -> (u, u * w16^i); then the two 8-point halves
+                NTT_MATH64(static_for<1, 8>([&](auto I) { constexpr int i = decltype(I)::value; v[8 + i] = f.twiddled(v[i], rF[i]); });
+                           v[8] = v[0];
+                           dif_sub<F, 3, 0, true>(v, f, rF); dif_sub<F, 3, 8, true>(v, f, rF); v[0] = f.settle(v[0]));
+            } else {
+                NTT_MATH64(dif_blocks<F, 4, true>(v, f, rF); v[0] = f.settle(v[0]));
+            }
 #pragma unroll
             for (int pos = 1; pos < 16; ++pos) NTT_MATH64(v[pos] = f.twiddled(v[pos], f.tw_from_mem(rtw[pos])));
 #pragma unroll

@@ -8,15 +8,17 @@ import numpy as np
 from ntt_amd.fourstep import plan_shape
 
 
-def emulated_fourstep_product(lib, a, b, p, world, to_dev, from_dev, torch, stream, pieces=2):
-    """Product of two numpy uint64 vectors of equal length through `world` emulated ranks; returns 2n-1 values."""
+def emulated_fourstep_product(lib, a, b, p, world, to_dev, from_dev, torch, stream, pieces=2, all_rows=False):
+    """Product of two numpy uint64 vectors of equal length through `world` emulated ranks; returns 2n-1 values.
+    all_rows: tell the loading pass that every row of the (zero-padded) slab holds data, which takes its general path
+    instead of the one that skips the padding half."""
     L = lib.lib
     n = len(a)
     lt, lr, lc = plan_shape(n, world)
     R, C = 1 << lr, 1 << lc
     Cl, Rl = C // world, R // world
     g = world.bit_length() - 1
-    rows_valid = min(R, -(-n // C))
+    rows_valid = R if all_rows else min(R, -(-n // C))
 
     def slabs(v):
         full = np.zeros(R * C, dtype=np.uint64); full[:n] = v

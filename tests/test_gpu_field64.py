@@ -114,7 +114,9 @@ def test_emulated_eight_rank_product_of_2_pow_24_equals_the_direct_one(gpu_lib):
     a = rng.integers(0, BIGP, n, dtype=np.uint64); b = rng.integers(0, BIGP, n, dtype=np.uint64)
     to_dev = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64).copy()).cuda()
     from_dev = lambda t: t.cpu().numpy().view(np.uint64).copy()
+    got_all = emulated_fourstep_product(gpu_lib, a, b, BIGP, 8, to_dev, from_dev, torch, torch.cuda.current_stream().cuda_stream, pieces=4, all_rows=True)
     got = emulated_fourstep_product(gpu_lib, a, b, BIGP, 8, to_dev, from_dev, torch, torch.cuda.current_stream().cuda_stream, pieces=4)
+    assert np.array_equal(got, got_all)      # the loading pass with and without its shortcut for the padding rows
     assert np.array_equal(got, gpu_mul64(gpu_lib, a, b, BIGP))
 
 
