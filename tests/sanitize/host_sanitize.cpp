@@ -92,7 +92,7 @@ int main() {
         }
     }
     // stand-alone transforms
-    for (int n : {1, 2, 64, 4096, 16384}) {
+    for (int n : {1, 2, 8, 32, 64, 4096, 8192, 16384, 1 << 18}) {
         std::vector<uint64_t> x(n), y(n);
         oracle_fill_random(x.data(), n, 998244353ull, n);
         y = x;
@@ -101,6 +101,30 @@ int main() {
         oracle_ntt(ref.data(), n, 0, 998244353ull, 3);
         CHECK(y == ref, "forward transform n=%d", n);
         CHECK(ntt_transform_u64(y.data(), n, 1, 998244353ull) == NTT_OK && y == x, "inverse transform n=%d", n);
+    }
+    // the same on 32-bit residues: several rows per call, batches that do not fill the last workgroup, a modulus without a
+    // 64th root of unity (radix-2 kernel)
+    for (uint32_t p : {998244353u, 1224736769u, 257u}) {
+        for (int n : {2, 16, 32, 256, 4096, 8192, 32768}) {
+            if ((p - 1) % (uint32_t)n) continue;
+            const size_t batch = 3;
+            std::vector<uint32_t> x(batch * n + 2, 0xCDCDCDCDu), y;
+            std::vector<uint64_t> tmp(n);
+            for (size_t r = 0; r < batch; ++r) {
+                oracle_fill_random(tmp.data(), n, p, 40 + r + n);
+                for (int i = 0; i < n; ++i) x[r * n + i] = (uint32_t)tmp[i];
+            }
+            y = x;
+            CHECK(ntt_transform_device_u32(y.data(), n, batch, 0, p, nullptr) == NTT_OK, "transform u32: %s", ntt_last_error());
+            for (size_t r = 0; r < batch; ++r) {
+                for (int i = 0; i < n; ++i) tmp[i] = x[r * n + i];
+                oracle_ntt(tmp.data(), n, 0, p, 3);
+                bool same = true;
+                for (int i = 0; i < n; ++i) same = same && y[r * n + i] == (uint32_t)tmp[i];
+                CHECK(same, "u32 forward transform n=%d p=%u row %zu", n, p, r);
+            }
+            CHECK(ntt_transform_device_u32(y.data(), n, batch, 1, p, nullptr) == NTT_OK && y == x, "u32 round trip n=%d p=%u", n, p);
+        }
     }
     // argument errors leave memory alone
     {
