@@ -161,7 +161,8 @@ uint32_t ntt_crt_prime(int prime_index);
  *   along the rows axis AND the twiddles w^(j*k) that join the two axes, in the same passes over memory.  Inverse: the
  *   mirror (twiddles first).  cols_local must be a power of two.  This plus one all-to-all plus
  * ntt64_fourstep_cols_device is the whole transform: it runs the remaining log_cols levels on the layout the
- *   all-to-all of column slabs leaves, without re-tiling: 2^log_parts parts (one per sending rank, at most 16),
+ *   all-to-all of column slabs leaves, without re-tiling: 2^log_parts parts (one per sending rank; the rank count is a
+ *   power of two and at most 16, i.e. log_parts <= 4 -- more ranks are refused with NTT_ERR_ARG),
  *   part_stride words apart, each holding `rows` rows of 2^(log_cols-log_parts) consecutive columns.  `rows` may be a
  *   sub-range of a part (pass d_rows + first_row * 2^(log_cols-log_parts)), so that arriving chunks can be transformed
  *   while later ones are still in flight.
