@@ -568,6 +568,9 @@ __device__ __forceinline__ void pair_transpose16(uint32_t (&r)[16], int lane) {
 #ifndef NTT_SMALL16_WAVES
 #define NTT_SMALL16_WAVES 1
 #endif
+#ifndef NTT_SMALL16_DIRECT_FROM
+#define NTT_SMALL16_DIRECT_FROM 6
+#endif
 template <bool LZ, typename TIn, typename TOut>
 __global__ void __launch_bounds__(CORE_T, NTT_SMALL16_WAVES) k_small16(const TIn* A, const TIn* Bp, TOut* out, size_t a_stride, size_t b_stride,
                                                     size_t out_stride, int n, int n_out, int logL, size_t batch,
@@ -579,6 +582,39 @@ __global__ void __launch_bounds__(CORE_T, NTT_SMALL16_WAVES) k_small16(const TIn
     const int ql = ((logL - 1) & 3) + 1;
     const size_t first = (size_t)blockIdx.x << (12 - logL);     // first product of this workgroup
     uint32_t a[16], b[16];
+    // From transform length 64 on, the first forward round takes its values straight from the operands and the last
+    // inverse round stores straight to the result (no staging copy through LDS, two barriers fewer, and the padding half
+    // of every transform is neither read nor run through its first butterfly level): n = 64 ... 2048 +26 ... +37 %,
+    // n = 17 ... 32 +30 ... +46 %.  At length 32 the runs a wavefront reads would be 8 bytes long (n = 16: 13 % slower than
+    // the staged copy), so the shortest length keeps the staging.
+    const bool direct = logL >= NTT_SMALL16_DIRECT_FROM;
+    // first round from the operands: values j + k * sub of product `first + blk`, k < 8 -- the upper half of a transform
+    // (k >= 8) is padding for every product (n <= L/2) and is not read
+    auto load_first_round = [&](int sub, int blk, int j) {
+        const size_t prod = first + (size_t)blk;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = j + k * sub;
+            const bool inside = prod < batch && idx < n;
+            a[k] = load_coeff<LZ>(A, inside ? prod * a_stride + (size_t)idx : 0, f, fc);
+            b[k] = load_coeff<LZ>(Bp, inside ? prod * b_stride + (size_t)idx : 0, f, fc);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool inside = prod < batch && j + k * sub < n;
+            a[k] = inside ? a[k] : 0u; b[k] = inside ? b[k] : 0u;
+        }
+    };
+    // last round to the result: its outputs are coefficients j + k * sub of product `first + blk`
+    auto store_last_round = [&](int sub, int blk, int j) {
+        const size_t prod = first + (size_t)blk;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = j + k * sub;
+            if (prod < batch && idx < n_out) out[prod * out_stride + idx] = (TOut)f.canon_fwd(f.mulw(a[k], scale_m));
+        }
+    };
+    if (!direct) {
     // operands -> LDS, zero padded (values beyond n, products beyond the batch).  All thirty-two loads of a thread are
     // requested before the first value is used, and none is conditional (padding reads the operand's first word and is
     // replaced by zero afterwards): loads inside a condition, each followed by its LDS write, waited for one another --
@@ -605,6 +641,7 @@ __global__ void __launch_bounds__(CORE_T, NTT_SMALL16_WAVES) k_small16(const TIn
         lb[s] = inside ? b[i] : 0u;
     }
     __syncthreads();
+    }
     if (logL <= 6) {
         // Transform lengths 32 and 64: after one register round over the four high levels a product lives in two or four
         // neighbouring lanes, and the remaining one or two levels, the pointwise product and their inverses run on
@@ -614,10 +651,16 @@ __global__ void __launch_bounds__(CORE_T, NTT_SMALL16_WAVES) k_small16(const TIn
         const int blk = t >> lb2, j = t & (sub - 1);
         const int e0 = (blk << logL) + j;
         uint32_t tw[16];
+        if (direct) {
+            load_first_round(sub, blk, j);
+            dif_reg<4, LZ, true, true>(a, f, fc.rootF, fc.rootFn);
+            dif_reg<4, LZ, true, true>(b, f, fc.rootF, fc.rootFn);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { const int s = small_slot(e0 + k * sub); a[k] = la[s]; b[k] = lb[s]; }
-        dif_reg<4, LZ, false, true>(a, f, fc.rootF, fc.rootFn);
-        dif_reg<4, LZ, false, true>(b, f, fc.rootF, fc.rootFn);
+            for (int k = 0; k < 16; ++k) { const int s = small_slot(e0 + k * sub); a[k] = la[s]; b[k] = lb[s]; }
+            dif_reg<4, LZ, false, true>(a, f, fc.rootF, fc.rootFn);
+            dif_reg<4, LZ, false, true>(b, f, fc.rootF, fc.rootFn);
+        }
         load_tw16(tw, rt.f[logL], j);
 #pragma unroll
         for (int pos = 1; pos < 16; ++pos) { a[pos] = f.mulw(a[pos], tw[pos]); b[pos] = f.mulw(b[pos], tw[pos]); }
@@ -641,12 +684,36 @@ __global__ void __launch_bounds__(CORE_T, NTT_SMALL16_WAVES) k_small16(const TIn
         for (int k = 1; k < 16; ++k) a[k] = f.mulw(a[k], tw[k]);
         if (LZ) a[0] = csub(a[0], f.B);
         dit_reg<4, LZ, true>(a, f, fc.rootI);
-        __syncthreads();     // every thread has taken its operands before the results overwrite them
+        if (direct) {
+            store_last_round(sub, blk, j);
+        } else {
+            __syncthreads();     // every thread has taken its operands before the results overwrite them
 #pragma unroll
-        for (int k = 0; k < 16; ++k) la[small_slot(e0 + k * sub)] = a[k];
+            for (int k = 0; k < 16; ++k) la[small_slot(e0 + k * sub)] = a[k];
+        }
     } else {
     // forward rounds
-    for (int bl = logL; bl > 4; bl -= 4) {
+    int bl0 = logL;
+    if (direct) {
+        // first round from the operands: rows of the upper half (k >= 8) are padding for every product (n <= L/2)
+        const int sub = 1 << (logL - 4);
+        const int blk = t >> (logL - 4), j = t & (sub - 1);
+        const int e0 = (blk << logL) + j;
+        load_first_round(sub, blk, j);
+        dif_reg<4, LZ, true, true>(a, f, fc.rootF, fc.rootFn);
+        dif_reg<4, LZ, true, true>(b, f, fc.rootF, fc.rootFn);
+        uint32_t tw[16];
+        load_tw16(tw, rt.f[logL], j);
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) {
+            if (pos) { a[pos] = f.mulw(a[pos], tw[pos]); b[pos] = f.mulw(b[pos], tw[pos]); }
+            const int s = small_slot(e0 + pos * sub);
+            la[s] = a[pos]; lb[s] = b[pos];
+        }
+        __syncthreads();
+        bl0 = logL - 4;
+    }
+    for (int bl = bl0; bl > 4; bl -= 4) {
         const int sub = 1 << (bl - 4);
         const int blk = t >> (bl - 4), j = t & (sub - 1);
         const int e0 = (blk << bl) + j;
@@ -697,10 +764,15 @@ __global__ void __launch_bounds__(CORE_T, NTT_SMALL16_WAVES) k_small16(const TIn
             a[k] = k ? f.mulw(v, tw[k]) : (LZ ? csub(v, f.B) : v);
         }
         dit_reg<4, LZ, true>(a, f, fc.rootI);
+        if (direct && bl == logL) {
+            store_last_round(sub, blk, j);       // scaled, canonical, straight out
+        } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) la[small_slot(e0 + k * sub)] = a[k];
+            for (int k = 0; k < 16; ++k) la[small_slot(e0 + k * sub)] = a[k];
+        }
     }
     }
+    if (direct) return;
     __syncthreads();
     // scale by L^-1 (and the factor the pointwise product left), canonical, first 2n-1 coefficients of every product
 #pragma unroll
