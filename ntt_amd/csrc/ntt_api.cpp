@@ -1140,8 +1140,12 @@ int product64_rows(const Plan64& pl, const uint64_t* a, size_t sa, const uint64_
     if (logL <= LOCAL64_LOG && fused_core_allowed()) {      // short products: one kernel, several products per workgroup
         const uint64_t n_chunks = ((uint64_t)rows + (LOCAL64_N >> logL) - 1) / (LOCAL64_N >> logL);
         const unsigned grid = (unsigned)(n_chunks < (1u << 20) ? n_chunks : (1u << 20));
-        NTT_LAUNCH_P("k64_short_mul", (k64_short_mul<F>), dim3(grid), dim3(LOCAL64_T), st, a, (uint64_t)sa, b, (uint64_t)sb, out, (uint64_t)so,
-                     (uint64_t)n, (uint64_t)(2 * n - 1), (uint64_t)rows, logL, scale_arg<F>(tw_word(pl, scale)), consts_of<F>(pl), pl.rt);
+        if (logL >= 6)   // first and last round straight from / to caller memory
+            NTT_LAUNCH_P("k64_short_mul", (k64_short_mul<F, true>), dim3(grid), dim3(LOCAL64_T), st, a, (uint64_t)sa, b, (uint64_t)sb, out, (uint64_t)so,
+                         (uint64_t)n, (uint64_t)(2 * n - 1), (uint64_t)rows, logL, scale_arg<F>(tw_word(pl, scale)), consts_of<F>(pl), pl.rt);
+        else
+            NTT_LAUNCH_P("k64_short_mul", (k64_short_mul<F, false>), dim3(grid), dim3(LOCAL64_T), st, a, (uint64_t)sa, b, (uint64_t)sb, out, (uint64_t)so,
+                         (uint64_t)n, (uint64_t)(2 * n - 1), (uint64_t)rows, logL, scale_arg<F>(tw_word(pl, scale)), consts_of<F>(pl), pl.rt);
         HIP_TRY(hipGetLastError());
         return NTT_OK;
     }

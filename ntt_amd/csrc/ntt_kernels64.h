@@ -588,8 +588,14 @@ __global__ void __launch_bounds__(LOCAL64_T) k64_core_mul(uint64_t* data, const 
 // in the same LDS buffer (A's values wait in registers), pointwise product, inverse levels, scaled canonical results
 // (n_out per row) to caller memory.  Same rounds as k64_local for chunks of several blocks.
 // ---------------------------------------------------------------------------
-template <class F>
-__global__ void __launch_bounds__(LOCAL64_T, F::SHORT_MUL_WAVES) k64_short_mul(const uint64_t* a, uint64_t a_stride, const uint64_t* b, uint64_t b_stride,
+// DIRECT (transform lengths from 64 on): the first round reads the operands itself -- words j + k * sub of product
+// row0 + blk, k < 8: the upper half of every transform is padding (n <= length / 2), so it is neither read nor converted
+// and the first butterfly level is a multiply -- and the last inverse round writes the results itself; otherwise both ends
+// are staged through LDS (the runs a wavefront would read are too short).  A template parameter, not a run-time switch,
+// and compiled for three waves per SIMD: at four the double-precision flavour spilled 40 registers and lost a quarter
+// of its rate; at three it gains 10 ... 49 % over the staged form.
+template <class F, bool DIRECT>
+__global__ void __launch_bounds__(LOCAL64_T, DIRECT ? 3 : F::SHORT_MUL_WAVES) k64_short_mul(const uint64_t* a, uint64_t a_stride, const uint64_t* b, uint64_t b_stride,
                                                            uint64_t* out, uint64_t out_stride, uint64_t n, uint64_t n_out, uint64_t rows,
                                                            int m, typename F::W scale, typename F::Consts fc, RoundTables64 rt) {
     typedef typename F::V V;
@@ -608,6 +614,38 @@ __global__ void __launch_bounds__(LOCAL64_T, F::SHORT_MUL_WAVES) k64_short_mul(c
         const uint64_t row0 = chunk * per_chunk;
         auto forward = [&](const uint64_t* src, uint64_t stride) {
             NTT_FENCE64();
+            int first_bb = m;
+            if constexpr (DIRECT) {
+                const int sub = 1 << (m - 4);
+                const int blk = t >> (m - 4), j = t & (sub - 1);
+                const int e0 = (blk << m) + j;
+                const uint64_t row = row0 + (uint64_t)blk;
+                for (int k0 = 0; k0 < 8; k0 += 4) {      // four loads in flight at a time: the conversions need registers of their own
+                    uint64_t word[4];
+                    NTT_FENCE64();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint64_t pos = (uint64_t)(j + (k0 + k) * sub);
+                        word[k] = src[(row < rows && pos < n) ? row * stride + pos : 0];
+                    }
+                    NTT_FENCE64();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const V r = f.from_raw(word[k]);
+                        v[k0 + k] = (row < rows && (uint64_t)(j + (k0 + k) * sub) < n) ? r : V(0);
+                    }
+                }
+                static_for<1, 8>([&](auto I) { constexpr int i = decltype(I)::value; v[8 + i] = f.twiddled(v[i], rF[i]); });
+                v[8] = v[0];
+                dif_sub<F, 3, 0>(v, f, rF); dif_sub<F, 3, 8>(v, f, rF);
+                const uint64_t* T = rt.f[m] + ((size_t)j << 4);
+#pragma unroll
+                for (int pos = 1; pos < 16; ++pos) v[pos] = f.twiddled(v[pos], f.tw_from_mem(T[pos]));
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[local_slot(e0 + k * sub)] = v[k];
+                __syncthreads();
+                first_bb = m - 4;
+            } else {
 #pragma unroll 4
             for (int i = 0; i < 16; ++i) {     // four loads in flight at a time: the conversions need registers of their own
                 int e = t + LOCAL64_T * i;
@@ -618,7 +656,8 @@ __global__ void __launch_bounds__(LOCAL64_T, F::SHORT_MUL_WAVES) k64_short_mul(c
                 lds[local_slot(e)] = (row < rows && pos < n) ? f.from_raw(src[row * stride + pos]) : V(0);
             }
             __syncthreads();
-            for (int bb = m; bb > 4; bb -= 4) {
+            }
+            for (int bb = first_bb; bb > 4; bb -= 4) {
                 NTT_FENCE64();
                 const int sub = 1 << (bb - 4);
                 const int blk = t >> (bb - 4), j = t & (sub - 1);
@@ -662,9 +701,19 @@ __global__ void __launch_bounds__(LOCAL64_T, F::SHORT_MUL_WAVES) k64_short_mul(c
                 v[k] = k ? f.twiddled(r, f.tw_from_mem(T[k])) : r;
             }
             dit_blocks<F, 4>(v, f, rI);
+            if (DIRECT && bb == m) {
+                const uint64_t row = row0 + (uint64_t)blk;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) lds[local_slot(e0 + k * sub)] = v[k];
+                for (int k = 0; k < 16; ++k) {
+                    const uint64_t pos = (uint64_t)(j + k * sub);
+                    if (row < rows && pos < n_out) out[row * out_stride + pos] = f.canon(f.twiddled(v[k], scale));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[local_slot(e0 + k * sub)] = v[k];
+            }
         }
+        if constexpr (!DIRECT) {
         __syncthreads();
         NTT_FENCE64();
 #pragma unroll 4
@@ -673,6 +722,7 @@ __global__ void __launch_bounds__(LOCAL64_T, F::SHORT_MUL_WAVES) k64_short_mul(c
             NTT_OPAQUE(e);
             const uint64_t row = row0 + ((uint64_t)e >> m), pos = (uint64_t)e & pos_mask;
             if (row < rows && pos < n_out) out[row * out_stride + pos] = f.canon(f.twiddled(lds[local_slot(e)], scale));
+        }
         }
         __syncthreads();   // the next chunk overwrites the LDS
     }
