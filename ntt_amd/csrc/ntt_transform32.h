@@ -193,6 +193,9 @@ __global__ void __launch_bounds__(256) k_ntt_outer2(uint32_t* work, T* natural, 
 //   inverse: natural in -> reorder (position e takes a[bitrev(e)]) -> decimation in time -> natural out, times scale_m
 //            (the Montgomery form of n^-1)
 // ---------------------------------------------------------------------------
+#ifndef NTT_TSMALL16_DIRECT_FROM
+#define NTT_TSMALL16_DIRECT_FROM 6
+#endif
 template <bool LZ, bool INVERSE, typename T>
 __global__ void __launch_bounds__(CORE_T) k_ntt_small16(T* data, int lg, size_t count, uint32_t scale_m, FieldConsts fc,
                                                         RoundTables32 rt) {
@@ -209,24 +212,10 @@ __global__ void __launch_bounds__(CORE_T) k_ntt_small16(T* data, int lg, size_t 
     uint32_t a[16];
     // position e = 16 t + i of a thread <-> natural position inside the workgroup's 4096 values
     auto natural_of = [&](int e) -> int { return (e & ~mask) | brev_low(e & mask, lg); };
+    const bool direct = lg >= NTT_TSMALL16_DIRECT_FROM;
     if (!INVERSE) {
-        T raw[16];      // all loads requested before the first use, none conditional (see k_small16)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { const int e = t + CORE_T * i; raw[i] = base[(size_t)e < avail ? e : 0]; }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int e = t + CORE_T * i;
-            NTT_OPAQUE(e);
-            const uint32_t v = reduce_any<LZ>(raw[i], f, fc);
-            la[small_slot(e)] = (size_t)e < avail ? v : 0u;
-        }
-        __syncthreads();
-        for (int bl = lg; bl > 4; bl -= 4) {
-            const int sub = 1 << (bl - 4);
-            const int blk = t >> (bl - 4), j = t & (sub - 1);
-            const int e0 = (blk << bl) + j;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = la[small_slot(e0 + k * sub)];
+        // One radix-16 round over blocks of 2^bl values: twiddle, then back to the same slots.
+        auto finish_round = [&](int bl, int e0, int sub, int j) {
             dif_reg<4, LZ, false, true>(a, f, fc.rootF, fc.rootFn);
             uint32_t tw[16];
             load_tw16(tw, rt.f[bl], j);
@@ -236,6 +225,43 @@ __global__ void __launch_bounds__(CORE_T) k_ntt_small16(T* data, int lg, size_t 
                 la[small_slot(e0 + pos * sub)] = a[pos];
             }
             __syncthreads();
+        };
+        int bl = lg;
+        T raw[16];      // all loads requested before the first use, none conditional (see k_small16)
+        if (direct) {
+            // first round straight from the caller's array: no staging pass and no barrier before it
+            const int sub = 1 << (bl - 4);
+            const int blk = t >> (bl - 4), j = t & (sub - 1);
+            const int e0 = (blk << bl) + j;
+            const bool valid = (size_t)e0 < avail;      // transforms are whole: one answer for all 16 values
+#pragma unroll
+            for (int k = 0; k < 16; ++k) raw[k] = base[valid ? e0 + k * sub : 0];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t v = reduce_any<LZ>(raw[k], f, fc);
+                a[k] = valid ? v : 0u;
+            }
+            finish_round(bl, e0, sub, j);
+            bl -= 4;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const int e = t + CORE_T * i; raw[i] = base[(size_t)e < avail ? e : 0]; }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int e = t + CORE_T * i;
+                NTT_OPAQUE(e);
+                const uint32_t v = reduce_any<LZ>(raw[i], f, fc);
+                la[small_slot(e)] = (size_t)e < avail ? v : 0u;
+            }
+            __syncthreads();
+        }
+        for (; bl > 4; bl -= 4) {
+            const int sub = 1 << (bl - 4);
+            const int blk = t >> (bl - 4), j = t & (sub - 1);
+            const int e0 = (blk << bl) + j;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = la[small_slot(e0 + k * sub)];
+            finish_round(bl, e0, sub, j);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) a[i] = la[small_slot((t << 4) + i)];
@@ -289,6 +315,14 @@ __global__ void __launch_bounds__(CORE_T) k_ntt_small16(T* data, int lg, size_t 
                 a[k] = k ? f.mulw(v, tw[k]) : (LZ ? csub(v, f.B) : v);
             }
             dit_reg<4, LZ, true>(a, f, fc.rootI);
+            if (direct && bl + 4 > lg) {
+                // last round straight to the caller's array
+                if ((size_t)e0 < avail) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) base[e0 + k * sub] = (T)f.canon_fwd(f.mulw(a[k], scale_m));
+                }
+                return;
+            }
 #pragma unroll
             for (int k = 0; k < 16; ++k) la[small_slot(e0 + k * sub)] = a[k];
         }
