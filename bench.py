@@ -68,7 +68,10 @@ def load_traffic(kernel, batch):
     """(HBM bytes per launch of `kernel`, source) from the newest committed PMC summary (profiles/traffic_*.json), which
     was collected at the batch size recorded in it (256 when absent); traffic is proportional to the batch.  The figure
     is static: it describes the kernels as they were when that profile was taken, not this run."""
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")), reverse=True):   # newest summary that has this kernel
+    def newest_headline_first(path):      # traffic_<tag>.json (the headline run of a tag) before traffic_<tag>_<workload>.json
+        tag, _, workload = os.path.basename(path)[len("traffic_"):-len(".json")].partition("_")
+        return (tag, workload == "")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")), key=newest_headline_first, reverse=True):   # newest summary that has this kernel
         try:
             with open(path) as f:
                 d = json.load(f)
