@@ -10,10 +10,12 @@ max-over-ranks clock are the only communication.  Rank 0 prints one JSON line.
 """
 import argparse
 import ctypes
+import faulthandler
 import glob
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -309,6 +311,9 @@ def main():
     ap.add_argument("--other-sizes", default=None,
                     help="sizes of the other configurations as n3,batch3,n4,batch4,log_n5 (default 4096,65536,131072,64,28; the CPU "
                          "rehearsal uses 256,8,1024,4,12)")
+    ap.add_argument("--others-deadline-s", type=float, default=240.0,
+                    help="with several ranks: seconds the other configurations may take before every rank gives them up and "
+                         "rank 0 prints the headline line without them")
     ap.add_argument("--lib", default=None, help="diagnostic: load this build of the library instead of the shipped one")
     ap.add_argument("--no-verify", action="store_true", help="diagnostic: skip the result checks (ablated builds)")
     ap.add_argument("--rehearse-cpu", action="store_true",
@@ -477,24 +482,6 @@ def main():
         copy_gbs = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
 
-    # The other configurations, timed by the same rank processes (collective across the ranks: every rank takes part).
-    others = None
-    run_others = not args.no_other_configs and (cpu or not args.lib)
-    if run_others:
-        from ntt_amd.workloads import RankClock
-        del a_sets, b_sets, ws
-        if not cpu:
-            torch.cuda.empty_cache()
-        if args.other_sizes:
-            v = [int(x) for x in args.other_sizes.split(",")]
-        else:
-            v = [256, 8, 1024, 4, 12] if cpu else [4096, 65536, 131072, 64, 28]
-        sizes = {"c3": {"n": v[0], "batch": v[1]}, "c4": {"n": v[2], "batch": v[3]}, "c5": {"log_n": v[4]}}
-        if world > 1:
-            dist.barrier()
-        clock = RankClock(torch, dist if world > 1 else None, dev, comm_dev)
-        others = other_configurations(torch, dist, lib, clock, sizes)
-
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * B / (elapsed / args.steps)
@@ -551,6 +538,63 @@ def main():
             line["rehearsal"] = "CPU twin over gloo: control-flow rehearsal, not a measurement"
         if collective_info is not None:
             line["rccl"] = collective_info
+
+    # The other configurations, timed by the same rank processes (collective across the ranks: every rank takes part).
+    # The headline line is complete by now.  Across ranks these workloads exchange data, and a rank that fails or stalls
+    # in one of them would leave the others waiting in a collective for ever: every rank therefore arms a deadline, and
+    # when it passes (or this rank's workloads raise) rank 0 prints the headline line with a note in place of the other
+    # configurations and the process ends at once, without waiting for the collective it is stuck in.
+    others = None
+    run_others = not args.no_other_configs and (cpu or not args.lib)
+    if run_others:
+        from ntt_amd.workloads import RankClock
+        del a_sets, b_sets, ws
+        if not cpu:
+            torch.cuda.empty_cache()
+        if args.other_sizes:
+            v = [int(x) for x in args.other_sizes.split(",")]
+        else:
+            v = [256, 8, 1024, 4, 12] if cpu else [4096, 65536, 131072, 64, 28]
+        sizes = {"c3": {"n": v[0], "batch": v[1]}, "c4": {"n": v[2], "batch": v[3]}, "c5": {"log_n": v[4]}}
+
+        once = threading.Lock()      # held for good by whoever prints the line
+
+        def abandon(reason):
+            if not once.acquire(blocking=False):
+                return
+            if rank == 0:
+                line["other_configs"] = [{"error": reason}]
+                print(json.dumps(line), flush=True)
+            sys.stderr.write(f"bench.py rank {rank}: other configurations abandoned: {reason}\n")
+            sys.stderr.flush()
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)      # where this rank was
+            os._exit(0)
+
+        deadline = None
+        if world > 1:
+            dist.barrier()
+            # rank 0 first, so that its line is out before any other rank's exit is noticed
+            deadline = threading.Timer(args.others_deadline_s + (0 if rank == 0 else 5),
+                                       abandon, [f"not finished within {args.others_deadline_s:.0f} s"])
+            deadline.daemon = True
+            deadline.start()
+        clock = RankClock(torch, dist if world > 1 else None, dev, comm_dev)
+        try:
+            others = other_configurations(torch, dist, lib, clock, sizes)
+        except Exception as e:      # world > 1 only (a single rank records the error per workload and goes on)
+            if rank == 0:
+                abandon(f"{type(e).__name__}: {e}")
+            sys.stderr.write(f"bench.py rank {rank}: {type(e).__name__}: {e}\n")
+            sys.stderr.flush()
+            while True:             # the other ranks are waiting for this one: the deadline ends all of them
+                time.sleep(1)
+        if deadline is not None:
+            deadline.cancel()
+            if not once.acquire(blocking=False):     # the deadline fired while the last workload returned: it ends the process
+                while True:
+                    time.sleep(1)
+
+    if rank == 0:
         if others is not None:
             line["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline and not cpu:

@@ -64,8 +64,21 @@ class RankClock:
             self.sync()
 
     def ramp(self, fn, seconds):
+        """Untimed calls for about `seconds`.  Across ranks every rank makes the SAME number of calls -- `fn` may hold a
+        collective, and ranks that each went by their own clock would part ways by one call and wait for each other for
+        ever: the count comes from the slowest rank's time for one call."""
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < seconds:
+        if self.dist is None:
+            while time.perf_counter() - t0 < seconds:
+                fn()
+                self.sync()
+            return
+        fn()
+        self.sync()
+        t = self.torch.tensor([time.perf_counter() - t0], dtype=self.torch.float64, device=self.comm_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        calls = min(int(seconds / max(float(t.item()), 1e-6)), 100000)
+        for _ in range(calls):
             fn()
             self.sync()
 

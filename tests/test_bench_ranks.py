@@ -58,3 +58,16 @@ def test_launcher_form_and_rank_mismatch():
     r = subprocess.run(base + ["--gpus", "1"] + SMALL, capture_output=True, text=True, timeout=300, env=clean_env(), cwd=ROOT)
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "--gpus 1 but the launcher started 2" in r.stderr
+
+
+def test_headline_line_survives_other_configurations_that_do_not_finish():
+    # a deadline shorter than any workload: every rank gives the other configurations up, rank 0 still prints the headline
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py")]
+    r = subprocess.run(base + ["--gpus", "2", "--others-deadline-s", "0.001"] + SMALL, capture_output=True, text=True,
+                       timeout=300, env=clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["verified_vs_oracle"] is True and d["value"] > 0
+    assert len(d["other_configs"]) == 1 and "not finished within" in d["other_configs"][0]["error"]
+    assert "other configurations abandoned" in r.stderr
