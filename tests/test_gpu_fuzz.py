@@ -1,9 +1,20 @@
 """Seeded random sweep over sizes, moduli, batch counts and row strides through the device entry points,
 each case against the reference algorithm (power-of-two n) or the 128-bit schoolbook product (other n)."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+# A longer soak of the same sweeps: NTT_FUZZ_SEED shifts every generator's seed, NTT_FUZZ_SCALE multiplies the case counts
+# (the defaults are what the suite runs).
+SEED_SHIFT = int(os.environ.get("NTT_FUZZ_SEED", "0"))
+SCALE = max(1, int(os.environ.get("NTT_FUZZ_SCALE", "1")))
+
+
+def seeded(seed):
+    return np.random.default_rng(seed + SEED_SHIFT)
 
 PRIMES32 = [7340033, 104857601, 469762049, 998244353, 1004535809, 1224736769]
 OTHER = [1337006139375617, 1000000007, 2**61 - 1, 2**64 - 59, 4294967311, 65537, 97, 2, 3, 6, 2**32]
@@ -18,11 +29,11 @@ def expected(oracle, a, b, p):
 
 def test_random_shapes_u64_device(gpu_lib, oracle, route):
     import torch
-    rng = np.random.default_rng(20240607)
+    rng = seeded(20240607)
     L = gpu_lib.lib
     st = torch.cuda.current_stream().cuda_stream
     sizes = [1, 2, 3, 5, 31, 32, 33, 100, 255, 256, 257, 1000, 2047, 2048, 2049, 3000, 4095, 4096, 4097, 6000, 8191, 8192]
-    for case in range(60):
+    for case in range(60 * SCALE):
         n = int(rng.choice(sizes)) if case % 3 else int(rng.integers(1, 3000))
         p = int(rng.choice(PRIMES32)) if case % 2 else int(OTHER[case // 2 % len(OTHER)])
         batch = int(rng.integers(1, 4))
@@ -44,10 +55,10 @@ def test_random_shapes_u64_device(gpu_lib, oracle, route):
 
 def test_random_shapes_u32_device(gpu_lib, oracle):
     import torch
-    rng = np.random.default_rng(77)
+    rng = seeded(77)
     L = gpu_lib.lib
     st = torch.cuda.current_stream().cuda_stream
-    for case in range(40):
+    for case in range(40 * SCALE):
         n = int(rng.integers(1, 9000)) if case % 2 else int(2 ** rng.integers(0, 16))
         p = int(rng.choice(PRIMES32))
         batch = int(rng.integers(1, 5))
@@ -72,11 +83,11 @@ def test_random_long_shapes_through_the_64bit_field(gpu_lib, oracle):
     padded rows, a caller workspace of exactly the advertised size, values at the top of the range."""
     import torch
     big = 1337006139375617
-    rng = np.random.default_rng(646464)
+    rng = seeded(646464)
     L = gpu_lib.lib
     st = torch.cuda.current_stream().cuda_stream
-    for case in range(8):
-        n = int(rng.integers(32769, 140000)) if case % 4 else [65536, 131072][case // 4]
+    for case in range(8 * SCALE):
+        n = int(rng.integers(32769, 140000)) if case % 4 else [65536, 131072][case // 4 % 2]
         p = big if case % 2 == 0 else int(rng.choice([998244353, 469762049]))
         batch = int(rng.integers(1, 4))
         sa, sb, so = n + int(rng.integers(0, 7)), n + int(rng.integers(0, 7)), 2 * n - 1 + int(rng.integers(0, 7))
@@ -116,11 +127,11 @@ def test_both_large_modulus_routes_agree_on_random_shapes(gpu_lib):
     n = 2^17, ragged lengths, padded rows, values up to p - 1, compared with each other bit for bit."""
     import torch
     big = 1337006139375617
-    rng = np.random.default_rng(31337)
+    rng = seeded(31337)
     L = gpu_lib.lib
     st = torch.cuda.current_stream().cuda_stream
     try:
-        for case in range(150):
+        for case in range(150 * SCALE):
             hi = [64, 5000, 131072][case % 3]
             n = int(rng.integers(1, hi + 1)) if case % 7 else int(2 ** rng.integers(0, hi.bit_length()))
             batch = int(rng.integers(1, 6)) if n > 20000 else int(rng.integers(1, 40))
@@ -142,3 +153,36 @@ def test_both_large_modulus_routes_agree_on_random_shapes(gpu_lib):
             assert bool((outs[0][:, 2 * n - 1:] == -1).all())
     finally:
         gpu_lib.set_route_policy("auto")
+
+
+def test_random_natural_order_transforms(gpu_lib, oracle):
+    """ntt_transform_device_u32 / _u64 on random lengths 2 .. 2^16, batch counts that fill neither a workgroup nor a
+    wavefront, both directions: every row against the reference's NTT() (main_naive.cc:96-137) for the shorter calls, a
+    sample of rows for the longer ones, and inverse(forward(x)) = x for all of them."""
+    import torch
+    rng = seeded(424242)
+    L = gpu_lib.lib
+    st = torch.cuda.current_stream().cuda_stream
+    for case in range(40 * SCALE):
+        lg = int(rng.integers(1, 17))
+        n = 1 << lg
+        p = int(rng.choice(PRIMES32))
+        batch = int(rng.integers(1, max(2, min(300, (1 << 18) >> lg))))
+        inv = int(rng.integers(0, 2))
+        x = rng.integers(0, p, (batch, n), dtype=np.uint64)
+        if case % 4 == 0:
+            x[batch - 1, :] = p - 1
+        rows = range(batch) if batch * n <= (1 << 14) else sorted({0, batch // 2, batch - 1})
+        t32 = torch.from_numpy(x.astype(np.uint32).view(np.int32)).cuda()
+        t64 = torch.from_numpy(x.view(np.int64).copy()).cuda()
+        gpu_lib.check(L.ntt_transform_device_u32(t32.data_ptr(), n, batch, inv, p, st))
+        gpu_lib.check(L.ntt_transform_device_u64(t64.data_ptr(), n, batch, inv, p, st))
+        torch.cuda.synchronize()
+        got32 = t32.cpu().numpy().view(np.uint32).astype(np.uint64)
+        got64 = t64.cpu().numpy().view(np.uint64)
+        assert np.array_equal(got32, got64), (case, lg, p, batch, inv)
+        for r in rows:
+            assert np.array_equal(got32[r], oracle.ntt(x[r], bool(inv), p)), (case, lg, p, batch, inv, r)
+        gpu_lib.check(L.ntt_transform_device_u32(t32.data_ptr(), n, batch, 1 - inv, p, st))
+        torch.cuda.synchronize()
+        assert np.array_equal(t32.cpu().numpy().view(np.uint32).astype(np.uint64), x), (case, lg, p, batch, inv)
