@@ -1028,7 +1028,6 @@ int transform64_split(const Plan64& pl, uint64_t* d, int log_cols, int log_parts
     if (log_cols > pl.log_root) return fail(NTT_ERR_ARG, "transform longer than the plan's root order");
     if (rows == 0) return NTT_OK;
     const int log_cl = log_cols - log_parts;
-    const uint64_t cl = (uint64_t)1 << log_cl;
     auto parts_pass = [&]() -> int {
         if (log_parts == 0) return NTT_OK;
         const Pass64 g = parts_pass_geometry(pl, log_cols, log_parts, part_stride, rows);

@@ -544,7 +544,7 @@ __device__ __forceinline__ int small_slot(int e) { return core_slot(e >> 8, (e >
 // of the pair (x0, x1) -- the lane whose bit D is clear gives x1 and takes the partner's x0, the other the other way round.
 template <int D>
 __device__ __forceinline__ void quad_pair_swap(uint32_t& x0, uint32_t& x1, int lane) {
-    constexpr int ctrl = D == 2 ? 0x4E : 0xB1;              // quad_perm [2,3,0,1] / [1,0,3,2]
+    [[maybe_unused]] constexpr int ctrl = D == 2 ? 0x4E : 0xB1;              // quad_perm [2,3,0,1] / [1,0,3,2]
     const bool up = (lane & D) != 0;
     const uint32_t give = up ? x0 : x1;
     const uint32_t got = NTT_QUAD_PERM(give, ctrl);
