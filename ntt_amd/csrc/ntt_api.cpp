@@ -396,14 +396,12 @@ void launch_crt_multipass(Plan* const (&pl)[4], const uint64_t* a, const uint64_
     else
         NTT_LAUNCH_P("k_fwd_strided_crt", (k_fwd_strided_crt<Q, FW, false, MINW>), dim3(fgrid, 1, 2), dim3(4 * FW), st, a, b, sa, sb, n,
                      CORE_N, fa);
+    CrtCoreArgs ca;
     for (int i = 0; i < 4; ++i) {
-        if (pl[i]->h.lazy)
-            NTT_LAUNCH_P("k_core_mul", (k_core_mul<true>), dim3((unsigned)(batch << Q)), dim3(CORE_T), st, (const uint32_t*)fa.outA[i],
-                         (const uint32_t*)fa.outB[i], fa.outA[i], pl[i]->h.fc, pl[i]->core);
-        else
-            NTT_LAUNCH_P("k_core_mul", (k_core_mul<false>), dim3((unsigned)(batch << Q)), dim3(CORE_T), st, (const uint32_t*)fa.outA[i],
-                         (const uint32_t*)fa.outB[i], fa.outA[i], pl[i]->h.fc, pl[i]->core);
+        ca.A[i] = fa.outA[i]; ca.B[i] = fa.outB[i]; ca.C[i] = fa.outA[i];
+        ca.fc[i] = pl[i]->h.fc; ca.tb[i] = pl[i]->core;
     }
+    NTT_LAUNCH_P("k_core_mul_crt", k_core_mul_crt, dim3((unsigned)(batch << Q), 4), dim3(CORE_T), st, ca);
     if (full)
         NTT_LAUNCH_P("k_inv_strided_crt", (k_inv_strided_crt<Q, CW, true>), dim3(grid), dim3(4 * CW), st, ia, out, so, 2 * n - 1, CORE_N, c);
     else
@@ -843,6 +841,8 @@ struct TileExtra {           // fusions of a product's first and last pass
     uint64_t* out = nullptr; uint64_t n_out = 0; uint64_t scale_word = 0; // inverse: scaled canonical output
     const uint64_t* other = nullptr;                                      // inverse local pass: pointwise product first
     uint64_t src_stride = 0, out_stride = 0;                              // rows of the operands / results in caller memory
+    // forward tile pass of a product: the same pass over the second operand's work array in the same launch
+    uint64_t* data2 = nullptr; const uint64_t* src2 = nullptr; uint64_t src_stride2 = 0;
 };
 
 // Where the passes of one transform live and which twiddles join them: the middle axis of [outer][2^log_len][inner].
@@ -889,12 +889,15 @@ int launch_pass(const Plan64& pl, uint64_t* d, bool tile, const Pass64& g, bool 
         if (tiles >= (1ull << 31)) return fail(NTT_ERR_ARG, "transform too large for one launch");
         const unsigned grid = (unsigned)tiles;
         const typename F::W scale = scale_arg<F>(ex.scale_word);
+        uint64_t* const no_d = nullptr;
+        const uint64_t* const no_s = nullptr;
         if (!inverse) {
-            if (ex.src) NTT_LAUNCH_P("k64_tile", (k64_tile<F, false, true, false>), dim3(grid), dim3(TILE64_T), st, d, ex.src, (uint64_t*)nullptr, (uint64_t)0, scale, g, fc, pl.tw, pl.rt);
-            else NTT_LAUNCH_P("k64_tile", (k64_tile<F, false, false, false>), dim3(grid), dim3(TILE64_T), st, d, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, scale, g, fc, pl.tw, pl.rt);
+            const dim3 grid2(grid, ex.data2 ? 2 : 1);      // both operands of a product in one launch
+            if (ex.src) NTT_LAUNCH_P("k64_tile", (k64_tile<F, false, true, false>), grid2, dim3(TILE64_T), st, d, ex.src, no_d, (uint64_t)0, scale, g, fc, pl.tw, pl.rt, ex.data2, ex.src2, (uint64_t)ex.src_stride2);
+            else NTT_LAUNCH_P("k64_tile", (k64_tile<F, false, false, false>), grid2, dim3(TILE64_T), st, d, no_s, no_d, (uint64_t)0, scale, g, fc, pl.tw, pl.rt, ex.data2, no_s, (uint64_t)0);
         } else {
-            if (ex.out) NTT_LAUNCH_P("k64_tile", (k64_tile<F, true, false, true>), dim3(grid), dim3(TILE64_T), st, d, (const uint64_t*)nullptr, ex.out, ex.n_out, scale, g, fc, pl.tw, pl.rt);
-            else NTT_LAUNCH_P("k64_tile", (k64_tile<F, true, false, false>), dim3(grid), dim3(TILE64_T), st, d, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, scale, g, fc, pl.tw, pl.rt);
+            if (ex.out) NTT_LAUNCH_P("k64_tile", (k64_tile<F, true, false, true>), dim3(grid), dim3(TILE64_T), st, d, no_s, ex.out, ex.n_out, scale, g, fc, pl.tw, pl.rt, no_d, no_s, (uint64_t)0);
+            else NTT_LAUNCH_P("k64_tile", (k64_tile<F, true, false, false>), dim3(grid), dim3(TILE64_T), st, d, no_s, no_d, (uint64_t)0, scale, g, fc, pl.tw, pl.rt, no_d, no_s, (uint64_t)0);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1172,14 +1175,21 @@ int product64_rows(const Plan64& pl, const uint64_t* a, size_t sa, const uint64_
     // inverse pass are one kernel
     const bool core = steps.back().q == LOCAL64_LOG && fused_core_allowed();
     const size_t n_outer = core ? steps.size() - 1 : steps.size();
-    for (int side = 0; side < 2; ++side) {
-        uint64_t* w = side ? wb : wa;
-        TileExtra first;
-        first.src = side ? b : a;
-        first.src_valid = n;
-        first.src_stride = side ? sb : sa;
-        for (size_t i = 0; i < n_outer; ++i)
-            if ((rc = run_step<F>(pl, w, steps[i], ax, false, i == 0 ? first : none, st)) != NTT_OK) return rc;
+    for (size_t i = 0; i < n_outer; ++i) {
+        if (steps[i].kind == Step64::TILE) {         // one launch takes the pass over both work arrays
+            TileExtra ex;
+            ex.data2 = wb;
+            if (i == 0) { ex.src = a; ex.src_stride = sa; ex.src2 = b; ex.src_stride2 = sb; ex.src_valid = n; }
+            if ((rc = run_step<F>(pl, wa, steps[i], ax, false, ex, st)) != NTT_OK) return rc;
+            continue;
+        }
+        for (int side = 0; side < 2; ++side) {
+            TileExtra first;
+            first.src = side ? b : a;
+            first.src_valid = n;
+            first.src_stride = side ? sb : sa;
+            if ((rc = run_step<F>(pl, side ? wb : wa, steps[i], ax, false, i == 0 ? first : none, st)) != NTT_OK) return rc;
+        }
     }
     if (core) {
         const uint64_t n_chunks = ((uint64_t)rows << logL) >> LOCAL64_LOG;
@@ -2414,7 +2424,7 @@ int ntt_describe_plan(int n, uint64_t p, char* buf, size_t buf_len) {
     const char* pipe = logL <= 12 ? ((logL >= 5 && p < (1ull << 31) && (p - 1) % 64 == 0) ? "k_small16" : "k_small") : logL == 13 ? "k_fused8192" : "k_fwd_strided,k_core_mul,k_inv_strided";
     if (route == ROUTE_DIRECT32) s = pipe;
     else if (route == ROUTE_CRT)
-        s = (logL >= 14 && crt_fused_merge_allowed()) ? std::string("k_fwd_strided_crt,4x(k_core_mul),k_inv_strided_crt")
+        s = (logL >= 14 && crt_fused_merge_allowed()) ? std::string("k_fwd_strided_crt,k_core_mul_crt,k_inv_strided_crt")
                                                       : std::string("4x(") + pipe + "),k_crt_merge";
     else if (route == ROUTE_FIELD64 || route == ROUTE_WIDECRT) {
         // the launches of one product in the 64-bit field, in order of first use

@@ -20,8 +20,8 @@
 //                         k_inv_strided (twiddle, radix-2^Q inverse columns, canonical store)
 //   four-prime CRT route  (moduli above 2^31 under the reference's route policy, and moduli that are not NTT-friendly)
 //     L >= 2^14           k_fwd_strided_crt (64-bit operands read once, residue step and forward column pass of all
-//                         four primes) -> k_core_mul per prime -> k_inv_strided_crt (inverse column pass of all four
-//                         primes and the recombination; the residues never reach memory)
+//                         four primes) -> k_core_mul_crt (the four cores, one launch) -> k_inv_strided_crt (inverse
+//                         column pass of all four primes and the recombination; the residues never reach memory)
 //     shorter             the single-kernel paths above once per prime on 64-bit inputs, then k_crt_merge
 //
 // Reference loops these replace: zero-pad/copy main_naive.cc:147-153, butterfly
@@ -227,6 +227,36 @@ __global__ void __launch_bounds__(CORE_T) k_core_mul(const uint32_t* tmpA, const
 #endif
     const size_t base = (size_t)blockIdx.x * CORE_N;
     core_block<LZ>(tmpA + base, tmpB + base, tmpC + base, lds, fc, tb, threadIdx.x);
+}
+
+// The fused core of the four CRT primes in one launch: blockIdx.y picks the prime (its arrays, constants and tables), so the
+// four cores of a product batch share one grid -- one ramp-up and one tail instead of four.  gridDim.x is a multiple of
+// eight, so a 4096-point row still runs on XCD (row mod 8) whichever prime it belongs to.
+struct CrtCoreArgs {
+    const uint32_t* A[4];
+    const uint32_t* B[4];
+    uint32_t* C[4];
+    FieldConsts fc[4];
+    CoreTables tb[4];
+};
+
+// One copy of the core per prime, each reading its constants at fixed offsets of the argument block (indexed by a run-time
+// prime number they would be fetched once and kept in vector registers: 165 instead of 119, one wavefront per SIMD fewer).
+// The second prime of the basis is the one above 2^30 (values kept fully reduced), as in the column passes below.
+template <int K>
+__device__ __forceinline__ void core_block_of_prime(const CrtCoreArgs& a, uint32_t* lds) {
+    const size_t base = (size_t)blockIdx.x * CORE_N;
+    core_block<K != 1>(a.A[K] + base, a.B[K] + base, a.C[K] + base, lds, a.fc[K], a.tb[K], threadIdx.x);
+}
+
+__global__ void __launch_bounds__(CORE_T) k_core_mul_crt(CrtCoreArgs a) {
+    __shared__ uint32_t lds[2 * CORE_N];
+    switch (blockIdx.y) {
+        case 0: core_block_of_prime<0>(a, lds); break;
+        case 1: core_block_of_prime<1>(a, lds); break;
+        case 2: core_block_of_prime<2>(a, lds); break;
+        default: core_block_of_prime<3>(a, lds); break;
+    }
 }
 
 // ---------------------------------------------------------------------------

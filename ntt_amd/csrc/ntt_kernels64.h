@@ -183,14 +183,19 @@ NTT_HD uint64_t bitrev64(uint64_t x, int bits) {
 //   beyond) from `src` instead of `data`.
 // FINAL (inverse only): the last round multiplies by `scale`, reduces to [0,p) and writes the first n_out elements of
 //   every row to `out` instead of `data`.
+// gridDim.y = 2 (forward only): the same pass over a second array (data2, src2, src_stride2) in the same launch -- the two
+//   operands of a product; one ramp-up and one tail instead of two.
 // ---------------------------------------------------------------------------
 template <class F, bool INVERSE, bool SRC_RAW, bool FINAL>
 __global__ void __launch_bounds__(TILE64_T, 4) k64_tile(uint64_t* data, const uint64_t* src, uint64_t* out, uint64_t n_out,
                                                      typename F::W scale, Pass64 g, typename F::Consts fc, Twiddle64 tw,
-                                                     RoundTables64 rt) {
+                                                     RoundTables64 rt, uint64_t* data2, const uint64_t* src2, uint64_t src_stride2) {
     typedef typename F::V V;
     typedef typename F::W W;
     __shared__ V lds[TILE64_N];
+    // forward passes of the two operands of a product in one launch: blockIdx.y = 1 works on the second array
+    uint64_t src_stride = g.src_stride;
+    if (!INVERSE && blockIdx.y) { data = data2; src = src2; src_stride = src_stride2; }
     const F f(fc);
     W rF[8], rI[8];
     load_roots<F>(rF, rI, fc);
@@ -259,7 +264,7 @@ __global__ void __launch_bounds__(TILE64_T, 4) k64_tile(uint64_t* data, const ui
             const int row0 = (blk << b) + j;
             uint64_t idx = origin + (uint64_t)row0 * step;
             const uint64_t dstep = (uint64_t)sub * step;
-            const uint64_t* src_row = SRC_RAW ? src + blk_g * g.src_stride : nullptr;   // uniform over the workgroup
+            const uint64_t* src_row = SRC_RAW ? src + blk_g * src_stride : nullptr;   // uniform over the workgroup
             uint64_t pos = col + (uint64_t)row0 * step;                                   // offset inside the block
             if (SRC_RAW) {
                 // The address is always a valid one and the zero is selected afterwards: a conditional load is compiled
