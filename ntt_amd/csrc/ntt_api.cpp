@@ -872,11 +872,12 @@ int launch_pass(const Plan64& pl, uint64_t* d, bool tile, const Pass64& g, bool 
         const typename F::W scale = scale_arg<F>(ex.scale_word);
         const uint64_t* no_src = nullptr;
         uint64_t* no_out = nullptr;
+        const dim3 grid2(grid, (!inverse && ex.data2) ? 2 : 1);      // both operands of a product in one launch
 #define NTT_REG_CASE(Q)                                                                                                                  \
-    if (inverse && ex.out) NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, true, false, true>), dim3(grid), dim3(256), st, d, no_src, ex.out, ex.n_out, scale, g, fc, pl.tw); \
-    else if (inverse) NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, true>), dim3(grid), dim3(256), st, d, no_src, no_out, (uint64_t)0, scale, g, fc, pl.tw);               \
-    else if (ex.src) NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, false, true, false>), dim3(grid), dim3(256), st, d, ex.src, no_out, (uint64_t)0, scale, g, fc, pl.tw);   \
-    else NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, false>), dim3(grid), dim3(256), st, d, no_src, no_out, (uint64_t)0, scale, g, fc, pl.tw)
+    if (inverse && ex.out) NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, true, false, true>), grid2, dim3(256), st, d, no_src, ex.out, ex.n_out, scale, g, fc, pl.tw, no_out, no_src, (uint64_t)0); \
+    else if (inverse) NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, true>), grid2, dim3(256), st, d, no_src, no_out, (uint64_t)0, scale, g, fc, pl.tw, no_out, no_src, (uint64_t)0);               \
+    else if (ex.src) NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, false, true, false>), grid2, dim3(256), st, d, ex.src, no_out, (uint64_t)0, scale, g, fc, pl.tw, ex.data2, ex.src2, (uint64_t)ex.src_stride2);   \
+    else NTT_LAUNCH_P("k64_strided", (k64_strided<F, Q, false>), grid2, dim3(256), st, d, no_src, no_out, (uint64_t)0, scale, g, fc, pl.tw, ex.data2, no_src, (uint64_t)0)
         switch (g.q) {
             case 1: NTT_REG_CASE(1); break;
             case 2: NTT_REG_CASE(2); break;
@@ -1176,19 +1177,14 @@ int product64_rows(const Plan64& pl, const uint64_t* a, size_t sa, const uint64_
     const bool core = steps.back().q == LOCAL64_LOG && fused_core_allowed();
     const size_t n_outer = core ? steps.size() - 1 : steps.size();
     for (size_t i = 0; i < n_outer; ++i) {
-        if (steps[i].kind == Step64::TILE) {         // one launch takes the pass over both work arrays
+        if (steps[i].kind == Step64::TILE || steps[i].kind == Step64::REG) {   // one launch takes the pass over both work arrays
             TileExtra ex;
             ex.data2 = wb;
             if (i == 0) { ex.src = a; ex.src_stride = sa; ex.src2 = b; ex.src_stride2 = sb; ex.src_valid = n; }
             if ((rc = run_step<F>(pl, wa, steps[i], ax, false, ex, st)) != NTT_OK) return rc;
-            continue;
-        }
-        for (int side = 0; side < 2; ++side) {
-            TileExtra first;
-            first.src = side ? b : a;
-            first.src_valid = n;
-            first.src_stride = side ? sb : sa;
-            if ((rc = run_step<F>(pl, side ? wb : wa, steps[i], ax, false, i == 0 ? first : none, st)) != NTT_OK) return rc;
+        } else {                                                               // the chunk pass when the fused core is switched off
+            if ((rc = run_step<F>(pl, wa, steps[i], ax, false, none, st)) != NTT_OK) return rc;
+            if ((rc = run_step<F>(pl, wb, steps[i], ax, false, none, st)) != NTT_OK) return rc;
         }
     }
     if (core) {

@@ -735,15 +735,20 @@ __global__ void __launch_bounds__(LOCAL64_T, DIRECT ? 3 : F::SHORT_MUL_WAVES) k6
 
 // ---------------------------------------------------------------------------
 // k64_strided: register-only pass, radix 2^Q (Q <= 4), one thread per column; any inner extent.
+// gridDim.y = 2 (forward only): the same pass over a second array in the same launch, as in k64_tile.
 // SRC_RAW (forward) / FINAL (inverse): as in k64_tile -- caller words in, scaled canonical values out, rows of a batch
 // addressed through the block index and the strides.
 // ---------------------------------------------------------------------------
 template <class F, int Q, bool INVERSE, bool SRC_RAW = false, bool FINAL = false>
 __global__ void __launch_bounds__(256) k64_strided(uint64_t* data, const uint64_t* src, uint64_t* out, uint64_t n_out,
-                                                   typename F::W scale, Pass64 g, typename F::Consts fc, Twiddle64 tw) {
+                                                   typename F::W scale, Pass64 g, typename F::Consts fc, Twiddle64 tw,
+                                                   uint64_t* data2, const uint64_t* src2, uint64_t src_stride2) {
     typedef typename F::V V;
     typedef typename F::W W;
     constexpr int R = 1 << Q;
+    // forward passes of the two operands of a product in one launch: blockIdx.y = 1 works on the second array
+    uint64_t src_stride = g.src_stride;
+    if (!INVERSE && blockIdx.y) { data = data2; src = src2; src_stride = src_stride2; }
     const F f(fc);
     W rF[8], rI[8];
     load_roots<F>(rF, rI, fc);
@@ -766,7 +771,7 @@ __global__ void __launch_bounds__(256) k64_strided(uint64_t* data, const uint64_
         for (int r = 0; r < R; ++r) {
             const uint64_t pos = col + (uint64_t)r * step;
             inside[r] = pos < g.src_valid;
-            word[r] = src[blk * g.src_stride + (inside[r] ? pos : 0)];
+            word[r] = src[blk * src_stride + (inside[r] ? pos : 0)];
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
