@@ -2419,9 +2419,12 @@ int ntt_describe_plan(int n, uint64_t p, char* buf, size_t buf_len) {
     const Route route = choose_route(p, (size_t)n, &why);
     const char* pipe = logL <= 12 ? ((logL >= 5 && p < (1ull << 31) && (p - 1) % 64 == 0) ? "k_small16" : "k_small") : logL == 13 ? "k_fused8192" : "k_fwd_strided,k_core_mul,k_inv_strided";
     if (route == ROUTE_DIRECT32) s = pipe;
-    else if (route == ROUTE_CRT)
+    else if (route == ROUTE_CRT) {
+        // the products run modulo the four primes of the basis (64 divides every p_i - 1), not modulo p
+        const char* per_prime = logL <= 12 ? (logL >= 5 ? "k_small16" : "k_small") : logL == 13 ? "k_fused8192" : "k_fwd_strided,k_core_mul,k_inv_strided";
         s = (logL >= 14 && crt_fused_merge_allowed()) ? std::string("k_fwd_strided_crt,k_core_mul_crt,k_inv_strided_crt")
-                                                      : std::string("4x(") + pipe + "),k_crt_merge";
+                                                      : std::string("4x(") + per_prime + "),k_crt_merge";
+    }
     else if (route == ROUTE_FIELD64 || route == ROUTE_WIDECRT) {
         // the launches of one product in the 64-bit field, in order of first use
         const std::vector<Step64> steps = plan_steps(logL, 1, 1);
