@@ -71,3 +71,16 @@ def test_headline_line_survives_other_configurations_that_do_not_finish():
     assert d["n_gpus"] == 2 and d["verified_vs_oracle"] is True and d["value"] > 0
     assert len(d["other_configs"]) == 1 and "not finished within" in d["other_configs"][0]["error"]
     assert "other configurations abandoned" in r.stderr
+
+
+def test_eight_ranks_time_every_configuration():
+    # the rank count of a whole node: the four other configurations across eight ranks (one prime per pair of ranks in the
+    # CRT split, a 64 x 128 four-step matrix), every verdict reduced over the ranks
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + SMALL, capture_output=True, text=True,
+                       timeout=600, env=clean_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["verified_vs_oracle"] is True and d["verification"]["all_ranks_ok"] is True
+    assert d["rccl"]["world_size"] == 8 and d["rccl"]["all_reduce_of_ones"] == 8.0
+    others = d["other_configs"]
+    assert len(others) == 4 and all(o["n_gpus"] == 8 and o["verified"] is True and len(o["rank_ms"]) == 2 for o in others), others
