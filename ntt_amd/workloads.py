@@ -130,11 +130,16 @@ def hbm_roofline(rate_per_gpu, model_bytes, moved_bytes, note=None, issue=None):
 BUTTERFLIES32_PER_S = 4.9e12
 
 
-def issue_bound(butterflies_per_product, rate_per_gpu, peak):
+# the same for the exact double-precision field of the 64-bit kernels (tools/ubench_bfly64.hip, five waves per SIMD: eleven
+# fp64 instructions per butterfly at four cycles each)
+BUTTERFLIES_FIELDD_PER_S = 3.37e12
+
+
+def issue_bound(butterflies_per_product, rate_per_gpu, peak, source="tools/ubench_bfly.hip"):
     return {"butterflies_per_product": butterflies_per_product, "peak_butterflies_per_s": peak,
             "achieved_butterflies_per_s": butterflies_per_product * rate_per_gpu,
             "frac": butterflies_per_product * rate_per_gpu / peak,
-            "source": "butterfly ceiling measured by tools/ubench_bfly.hip (static)"}
+            "source": f"butterfly ceiling measured by {source} (static)"}
 
 
 def small_batched(torch, lib, clock, n=4096, p=998244353, batch=65536, reps=10, verify=None):
@@ -186,7 +191,8 @@ def large_modulus(torch, lib, clock, n=131072, p=BIG_P, batch=64, reps=20, polic
             "x 4 + inverse column pass of the four primes with the merge in it 48n" if crt else
             "three transforms of one 64-bit array: operand passes 24n + 24n, fused core 48n, result pass 32n; the core is bound by vector issue")
     bfly = 3 * (L // 2) * (L.bit_length() - 1)
-    issue = issue_bound(4 * bfly, rate, BUTTERFLIES32_PER_S) if crt else None
+    issue = (issue_bound(4 * bfly, rate, BUTTERFLIES32_PER_S) if crt
+             else issue_bound(bfly, rate, BUTTERFLIES_FIELDD_PER_S, "tools/ubench_bfly64.hip"))
     route = "four-prime CRT, the reference's route" if crt else "direct 64-bit field, default route"
     entry = {"config": f"large modulus n={n}, {batch} products per GPU ({route})", "n": n, "p": p, "batch_per_gpu": batch,
              "n_gpus": clock.world, "scaling": "weak", "ms_per_call": dt * 1e3, "rank_ms": [s * 1e3 for s in spread],
@@ -259,7 +265,8 @@ def long_product_direct(torch, lib, clock, log_n=28, p=BIG_P, reps=3, verify=Non
              "ms_per_call": dt * 1e3, "rank_ms": [s * 1e3 for s in spread], "poly_mults_per_s": 1.0 / dt,
              "kernels": lib.describe_plan(min(n, 1 << 30), p),
              "roofline": hbm_roofline(1.0 / dt, model, model,
-                                      "3 transforms x 2 passes x 16 B x L (the two-pass four-step model); the fused core is bound by vector issue")}
+                                      "3 transforms x 2 passes x 16 B x L (the two-pass four-step model); the fused core is bound by vector issue",
+                                      issue_bound(3 * (L // 2) * (L.bit_length() - 1), 1.0 / dt, BUTTERFLIES_FIELDD_PER_S, "tools/ubench_bfly64.hip"))}
     if verify is not None:
         entry["verified"] = clock.all_ok(verify(a, b, c, p))
     return entry
@@ -292,7 +299,9 @@ def long_product(torch, lib, clock, log_n=28, p=BIG_P, reps=3, chunks=4, verify=
                           "bytes_sent_per_rank_per_exchange": (world - 1) * fs.Rl * fs.Cl * 8, "stream_ordered": fs.stream_ordered},
              "roofline": hbm_roofline(1.0 / dt, per_gpu_model, per_gpu_model,
                                       "per GPU: its share of 3 transforms x 2 passes x 16 B x L (the two-pass four-step model); the fused core is "
-                                      "bound by vector issue")}
+                                      "bound by vector issue",
+                                      issue_bound(3 * (L // 2) * (L.bit_length() - 1) // world, 1.0 / dt, BUTTERFLIES_FIELDD_PER_S,
+                                                  "tools/ubench_bfly64.hip"))}
     if verify is not None:
         entry["verified"] = clock.all_ok(verify(fs, a, b, state["c"], p))
     return entry
